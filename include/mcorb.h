@@ -1,0 +1,211 @@
+/*
+ * mcorb.h -- C ABI of libmcorb, the MI355X (gfx950) multi-camera ORB front-end.
+ *
+ * Drop-in boundary for MC-SLAM's hot path.  Every entry point
+ * names the reference interface it replaces (paths relative to the MC-SLAM
+ * checkout).  Plain pointers and sizes only; no C++ types, no exceptions; every
+ * call returns a status code (0 ok, <0 error) unless stated otherwise.
+ *
+ * All compute runs in hand-written HIP kernels on the selected device; the
+ * library has no CPU fallback and fails with MCORB_E_NODEVICE / MCORB_E_HIP
+ * when no gfx950 device can be used.  The one host-side stage is the quad-tree
+ * keypoint selection (DistributeOctTree), which the reference's own design
+ * makes serial and order-defining; it runs on a host worker pool between two
+ * GPU phases (DESIGN.md "Selection").
+ */
+#ifndef MCORB_H
+#define MCORB_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MCORB_OK 0
+#define MCORB_E_EMPTY (-1)     /* empty image: the reference's `return -1` (ORBextractor.cpp:1090-1091) */
+#define MCORB_E_SIZE (-2)      /* image too small / too tall: the reference's cell or root-node
+                                  arithmetic would divide by zero (ORBextractor.cpp:558,799-802) */
+#define MCORB_E_CAP (-3)       /* caller buffer too small */
+#define MCORB_E_ARG (-4)       /* bad argument */
+#define MCORB_E_HIP (-5)       /* HIP runtime error, see mcorb_last_error() */
+#define MCORB_E_NODEVICE (-6)  /* no usable gfx950 device */
+#define MCORB_E_STATE (-7)     /* call out of order (e.g. match before extract) */
+#define MCORB_E_OVERFLOW (-8)  /* internal candidate buffer overflow (raise cand_cap) */
+
+#define MCORB_MAX_LEVELS 16
+#define MCORB_MAX_CAMS 16      /* IntraMatch::matchIndex is array<int,5> in the reference
+                                  (MultiCameraFrame.h:44); widened here for the 8-camera rig */
+#define MCORB_ORIENT_NONE 0    /* reference behaviour: angle = 0 (ORBextractor.cpp:475) */
+#define MCORB_ORIENT_IC_ANGLE 1 /* the reference's dormant IC_Angle (ORBextractor.cpp:75-102) */
+
+/* Field order is bit-compatible with cv::KeyPoint (pt.x, pt.y, size, angle,
+ * response, octave, class_id), the element type of the reference's outputs. */
+typedef struct mcorb_keypoint {
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} mcorb_keypoint;
+
+/* Constructor arguments of ORBextractor (ORBextractor.h:49-50) plus placement. */
+typedef struct mcorb_params {
+    int nfeatures;        /* ORBextractor.nFeatures */
+    float scale_factor;   /* ORBextractor.scaleFactor */
+    int nlevels;          /* ORBextractor.nLevels, 1..MCORB_MAX_LEVELS */
+    int ini_th_fast;      /* ORBextractor.iniThFAST */
+    int min_th_fast;      /* ORBextractor.minThFAST */
+    int orientation;      /* MCORB_ORIENT_* */
+    int device_id;        /* HIP device ordinal */
+    int host_threads;     /* selection workers; 0 = one per camera image, capped at hw concurrency */
+    int cand_cap;         /* FAST candidates kept per image; 0 = default (65536) */
+    int reserved[7];
+} mcorb_params;
+
+void mcorb_default_params(mcorb_params *p);   /* 2000, 1.2, 8, 20, 7, none, dev 0 */
+const char *mcorb_last_error(void);           /* thread-local message of the last failure */
+const char *mcorb_version(void);
+/* number of visible HIP devices whose arch is gfx950 (does not create a context) */
+int mcorb_device_count(void);
+
+/* ------------------------------------------------------------------------- */
+/* Rig engine: one object per GPU, handles a batch of equally sized images    */
+/* (cameras x frames).  Replaces MultiCameraFrame's extract + intra-rig match */
+/* members (MultiCameraFrame.h:73-90) and the frame hand-off of               */
+/* MultiCameraFrame::setData (MultiCameraFrame.cpp:95-152).                   */
+/* ------------------------------------------------------------------------- */
+typedef struct mcorb_rig mcorb_rig;
+
+/* ncams cameras of width x height; up to max_frames rig frames per batch
+ * (images are indexed m = frame*ncams + cam); nslots >= 1 independent buffer
+ * sets so that batches can be in flight concurrently (submit/wait below). */
+int mcorb_rig_create(const mcorb_params *p, int ncams, int width, int height, int max_frames,
+                     int nslots, mcorb_rig **out);
+void mcorb_rig_destroy(mcorb_rig *r);
+
+/* Stage `nimg` 8-bit gray images (host, stride bytes per row) into slot's
+ * level-0 planes through pinned buffers + hipMemcpyAsync.  Replaces the u8 end
+ * of the hand-off (MultiCameraFrame.cpp:108-140). */
+int mcorb_rig_upload_u8(mcorb_rig *r, int slot, const uint8_t *const *images, int nimg, int stride);
+/* Same for the reference's staging format: CV_32F in [0,1], 1 or 3 (BGR)
+ * channels (DatasetReader.cpp:699-712); x255, round-half-even, saturate and
+ * BGR2GRAY run on the device. */
+int mcorb_rig_upload_f32(mcorb_rig *r, int slot, const float *const *images, int nimg,
+                         int stride_bytes, int channels);
+
+/* extractFeaturesParallel (MultiCameraFrame.cpp:203-262) for the `nimg` images
+ * already resident in `slot`: pyramid, FAST, selection, blur, descriptors.
+ * lap_x0/lap_x1 = vLappingArea (ORBextractor.cpp:1153), {0,0} in the reference.
+ * submit returns once the first GPU phase is enqueued; wait blocks until
+ * keypoints and descriptors of the slot are complete on host and device. */
+int mcorb_rig_extract_submit(mcorb_rig *r, int slot, int nimg, int lap_x0, int lap_x1);
+int mcorb_rig_extract_wait(mcorb_rig *r, int slot);
+/* submit + wait */
+int mcorb_rig_extract(mcorb_rig *r, int slot, int nimg, int lap_x0, int lap_x1);
+
+/* One pass of the whole hot path for `nframes` rig frames (nframes*ncams images
+ * resident in the slot): extraction as above, then the intra-rig match below,
+ * with a single device synchronisation at the end. */
+int mcorb_rig_process_submit(mcorb_rig *r, int slot, int nframes, int lap_x0, int lap_x1,
+                             float dist_thresh, float ratio);
+int mcorb_rig_process_wait(mcorb_rig *r, int slot);
+
+/* results of image m of a slot: ORBextractor::operator() outputs
+ * (ORBextractor.cpp:1085-1171): keypoints, N x 32 descriptors, monoIndex */
+int mcorb_rig_num_keypoints(mcorb_rig *r, int slot, int m);
+int mcorb_rig_get_features(mcorb_rig *r, int slot, int m, mcorb_keypoint *kps, uint8_t *desc, int cap,
+                           int *n_out, int *mono_index_out);
+
+/* computeIntraMatches(matches, false) (MultiCameraFrame.cpp:1100-1288) for the
+ * first `nframes` rig frames of a slot: BruteForceMatch(i, j, dist_thresh,
+ * ratio) for all i<j on the GPU (all-pairs Hamming k-NN, k = 2), then the
+ * reference's track merge on the host. */
+int mcorb_rig_match(mcorb_rig *r, int slot, int nframes, float dist_thresh, float ratio);
+int mcorb_rig_match_submit(mcorb_rig *r, int slot, int nframes, float dist_thresh, float ratio);
+int mcorb_rig_match_wait(mcorb_rig *r, int slot);
+/* BruteForceMatch outputs of pair (cam_i < cam_j) of a frame: indices_1/2
+ * (MultiCameraFrame.cpp:1070-1071); kps1/kps2 are kps[idx] of the two images */
+int mcorb_rig_get_pair_matches(mcorb_rig *r, int slot, int frame, int cam_i, int cam_j,
+                               uint32_t *idx1, uint32_t *idx2, int cap, int *n_out);
+/* raw knnMatch(k=2) table of the pair, nq x 2 (trainIdx, distance); -1 = absent */
+int mcorb_rig_get_pair_knn2(mcorb_rig *r, int slot, int frame, int cam_i, int cam_j,
+                            int32_t *idx, int32_t *dist, int cap_rows, int *nq_out);
+/* IntraMatch tracks of a frame: ntracks x ncams matchIndex rows, -1 = absent;
+ * mergeable = cnt_mergable_matches (MultiCameraFrame.cpp:1256) */
+int mcorb_rig_get_tracks(mcorb_rig *r, int slot, int frame, int32_t *tracks, int cap_tracks,
+                         int *ntracks_out, int *mergeable_out);
+
+/* intermediates for stage-by-stage parity tests (device -> host copies) */
+int mcorb_rig_level_size(mcorb_rig *r, int level, int *w, int *h);
+int mcorb_rig_get_level(mcorb_rig *r, int slot, int m, int level, uint8_t *dst, int dst_stride);
+int mcorb_rig_get_blurred(mcorb_rig *r, int slot, int m, int level, uint8_t *dst, int dst_stride);
+/* vToDistributeKeys of a level (ORBextractor.cpp:793-871): packed (y<<20 | x<<8 | response) */
+int mcorb_rig_get_candidates(mcorb_rig *r, int slot, int m, int level, uint32_t *packed, int cap, int *n_out);
+
+/* timing of the last completed extract/match of a slot, microseconds of GPU
+ * time between HIP events on the slot's stream: [0] pyramid+FAST phase,
+ * [1] host selection wall time, [2] blur+descriptor phase, [3] match phase */
+int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[4]);
+
+/* multi-GPU plumbing: raw device pointers/stream of a slot so that a caller's
+ * collective (RCCL all-gather) can move per-camera descriptors between ranks.
+ * Descriptor block layout: [max_images][kcap][32] bytes, counts int32[max_images]. */
+int mcorb_rig_kcap(mcorb_rig *r);
+void *mcorb_rig_desc_device_ptr(mcorb_rig *r, int slot);
+void *mcorb_rig_stream(mcorb_rig *r, int slot);
+/* All-pairs k-NN (k=2) on caller-provided device memory: `desc_dev` holds
+ * ntotal descriptor sets [ntotal][kcap][32]; counts are host ints; pairs are
+ * (query set, train set) indices.  Results as mcorb_rig_get_pair_knn2, host
+ * arrays of npairs x kcap x 2.  Used by the RCCL path after the all-gather. */
+int mcorb_rig_knn2_external(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts,
+                            int ntotal, const int32_t *pairs_qt, int npairs,
+                            int32_t *idx, int32_t *dist);
+
+/* ------------------------------------------------------------------------- */
+/* Single-camera extractor: ORBextractor (ORBextractor.h:43-116)              */
+/* ------------------------------------------------------------------------- */
+typedef struct mcorb_extractor mcorb_t;
+
+/* ORBextractor::ORBextractor (ORBextractor.cpp:408-468); buffers are sized for
+ * images up to max_width x max_height (geometry is rebuilt when the size changes) */
+int mcorb_create(const mcorb_params *p, int max_width, int max_height, mcorb_t **out);
+void mcorb_destroy(mcorb_t *e);
+/* ORBextractor::operator() (ORBextractor.cpp:1085-1171); the mask argument of
+ * the reference is ignored there and absent here.  Returns MCORB_OK and
+ * *mono_index_out = the reference's return value, or MCORB_E_EMPTY for the
+ * reference's -1. */
+int mcorb_extract(mcorb_t *e, const uint8_t *gray, int w, int h, int stride_bytes,
+                  int lap_x0, int lap_x1, mcorb_keypoint *kps, uint8_t *desc, int cap,
+                  int *n_out, int *mono_index_out);
+/* same, fed with the reference's CV_32F [0,1] frame (setData, MultiCameraFrame.cpp:108-116) */
+int mcorb_extract_f32(mcorb_t *e, const float *img01, int w, int h, int stride_bytes, int channels,
+                      int lap_x0, int lap_x1, mcorb_keypoint *kps, uint8_t *desc, int cap,
+                      int *n_out, int *mono_index_out);
+/* GetLevels / GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares /
+ * GetInverseScaleSigmaSquares (ORBextractor.h:61-81) + mnFeaturesPerLevel */
+int mcorb_get_tables(const mcorb_params *p, float *scale, float *inv_scale, float *sigma2,
+                     float *inv_sigma2, int *features_per_level);
+/* mvImagePyramid[level] interior of the last call (ORBextractor.h:89) */
+int mcorb_get_pyramid_level(mcorb_t *e, int level, uint8_t *dst, int dst_stride, int *w, int *h);
+
+/* ------------------------------------------------------------------------- */
+/* Descriptor distance / matchers                                             */
+/* ------------------------------------------------------------------------- */
+/* ORBextractor::DescriptorDistance (ORBextractor.cpp:1202-1218); host, 0..256 */
+int mcorb_hamming256(const uint8_t a[32], const uint8_t b[32]);
+/* DescriptorMatcher("BruteForce-Hamming")->knnMatch(q, t, out, 2)
+ * (MultiCameraFrame.cpp:1053-1055; FrontEnd.cpp findInterMatches): host
+ * descriptor arrays in, nq x 2 (trainIdx, distance) out, -1 = absent. */
+int mcorb_knn2(mcorb_t *e, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist);
+/* BruteForceMatch (MultiCameraFrame.cpp:1024-1086): knn2 + ratio/threshold filter */
+int mcorb_match_ratio(mcorb_t *e, const uint8_t *q, int nq, const uint8_t *t, int nt,
+                      float dist_thresh, float ratio, uint32_t *idx1, uint32_t *idx2, int cap, int *n_out);
+
+/* ------------------------------------------------------------------------- */
+/* Synthetic input; host utility, see csrc/mcorb_synth.c       */
+/* ------------------------------------------------------------------------- */
+int mcorb_synth_rig_frame(uint32_t frame, int ncams, int cam, int w, int h, uint8_t *out, int stride);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,376 @@
+"""mc-slam_amd -- MI355X-native multi-camera ORB front-end (host-side mirror).
+
+Python mirrors of the reference interfaces this path replaces, all thin wrappers
+over the C ABI of libmcorb.so (include/mcorb.h):
+
+  ORBextractor        MCSlam/include/MCSlam/ORBextractor.h:43-116
+  MultiCameraFrame    MCSlam/include/MCSlam/MultiCameraFrame.h:59-92 (extract + intra-rig match members)
+  Rig                 batch/async engine underneath (cameras x frames per launch)
+
+The directory name is not a Python identifier; import it with
+``importlib.import_module("mc-slam_amd")`` or through the ``mcorb`` shim at the
+repository root.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import (E_ARG, E_CAP, E_EMPTY, E_HIP, E_NODEVICE, E_OVERFLOW, E_SIZE, E_STATE, KP_DTYPE, OK,
+                   ORIENT_IC_ANGLE, ORIENT_NONE, McorbError, Params, default_params)
+from .synth import synth_rig_frame, synth_rig_frame_numpy
+
+TH_HIGH = 100   # ORBextractor.h:26
+TH_LOW = 75     # ORBextractor.h:27
+HISTO_LENGTH = 30
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def device_count():
+    return _lib.load().mcorb_device_count()
+
+
+def get_tables(params):
+    """Scale tables + per-level quotas (ORBextractor.cpp:413-444)."""
+    n = params.nlevels
+    sc, isc, s2, is2 = (np.zeros(n, np.float32) for _ in range(4))
+    q = np.zeros(n, np.int32)
+    _lib.check(_lib.load().mcorb_get_tables(C.byref(params), sc.ctypes.data, isc.ctypes.data, s2.ctypes.data,
+                                            is2.ctypes.data, q.ctypes.data))
+    return dict(scale=sc, inv_scale=isc, sigma2=s2, inv_sigma2=is2, quota=q)
+
+
+def hamming256(a, b):
+    """ORBextractor::DescriptorDistance (ORBextractor.cpp:1202-1218)."""
+    a, b = _u8(a).reshape(32), _u8(b).reshape(32)
+    return _lib.load().mcorb_hamming256(a.ctypes.data, b.ctypes.data)
+
+
+class Rig:
+    """One engine per GPU: `ncams` cameras of w x h, up to `max_frames` rig frames per batch."""
+
+    def __init__(self, ncams, width, height, max_frames=1, nslots=1, params=None, **kw):
+        self.L = _lib.load()
+        self.params = params if params is not None else default_params(**kw)
+        self.ncams, self.w, self.h, self.max_frames, self.nslots = ncams, width, height, max_frames, nslots
+        h = C.c_void_p()
+        _lib.check(self.L.mcorb_rig_create(C.byref(self.params), ncams, width, height, max_frames, nslots, C.byref(h)))
+        self.h_rig = h
+        self.kcap = self.L.mcorb_rig_kcap(h)
+        self.nlevels = self.params.nlevels
+
+    def close(self):
+        if getattr(self, "h_rig", None):
+            self.L.mcorb_rig_destroy(self.h_rig)
+            self.h_rig = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- staging ------------------------------------------------------------
+    def upload(self, images, slot=0):
+        """images: list of HxW uint8 arrays (u8 fast path) or float32 [0,1] HxW / HxWx3 (reference format)."""
+        first = np.asarray(images[0])
+        if first.dtype == np.uint8:
+            arrs = [_u8(im) for im in images]
+            for a in arrs:
+                if a.shape != (self.h, self.w):
+                    raise ValueError("image shape %s != (%d,%d)" % (a.shape, self.h, self.w))
+            ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+            _lib.check(self.L.mcorb_rig_upload_u8(self.h_rig, slot, ptrs, len(arrs), self.w))
+        else:
+            arrs = [np.ascontiguousarray(im, dtype=np.float32) for im in images]
+            ch = 1 if arrs[0].ndim == 2 else arrs[0].shape[2]
+            ptrs = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+            _lib.check(self.L.mcorb_rig_upload_f32(self.h_rig, slot, ptrs, len(arrs), arrs[0].strides[0], ch))
+        return len(arrs)
+
+    # -- extraction ---------------------------------------------------------
+    def extract(self, nimg, slot=0, lap=(0, 0)):
+        _lib.check(self.L.mcorb_rig_extract(self.h_rig, slot, nimg, lap[0], lap[1]))
+
+    def extract_submit(self, nimg, slot=0, lap=(0, 0)):
+        _lib.check(self.L.mcorb_rig_extract_submit(self.h_rig, slot, nimg, lap[0], lap[1]))
+
+    def extract_wait(self, slot=0):
+        _lib.check(self.L.mcorb_rig_extract_wait(self.h_rig, slot))
+
+    def process_submit(self, nframes, slot=0, lap=(0, 0), dist_thresh=75.0, ratio=0.85):
+        _lib.check(self.L.mcorb_rig_process_submit(self.h_rig, slot, nframes, lap[0], lap[1], dist_thresh, ratio))
+
+    def process_wait(self, slot=0):
+        _lib.check(self.L.mcorb_rig_process_wait(self.h_rig, slot))
+
+    def features(self, m, slot=0):
+        n = self.L.mcorb_rig_num_keypoints(self.h_rig, slot, m)
+        if n < 0:
+            _lib.check(n)
+        kps = np.zeros(n, KP_DTYPE)
+        desc = np.zeros((n, 32), np.uint8)
+        nn, mono = C.c_int(), C.c_int()
+        _lib.check(self.L.mcorb_rig_get_features(self.h_rig, slot, m, kps.ctypes.data, desc.ctypes.data, n,
+                                                 C.byref(nn), C.byref(mono)))
+        return mono.value, kps, desc
+
+    # -- matching -----------------------------------------------------------
+    def match(self, nframes, slot=0, dist_thresh=75.0, ratio=0.85):
+        _lib.check(self.L.mcorb_rig_match(self.h_rig, slot, nframes, dist_thresh, ratio))
+
+    def pair_matches(self, frame, i, j, slot=0):
+        i1 = np.zeros(self.kcap, np.uint32)
+        i2 = np.zeros(self.kcap, np.uint32)
+        n = C.c_int()
+        _lib.check(self.L.mcorb_rig_get_pair_matches(self.h_rig, slot, frame, i, j, i1.ctypes.data, i2.ctypes.data,
+                                                     self.kcap, C.byref(n)))
+        return i1[:n.value].copy(), i2[:n.value].copy()
+
+    def pair_knn2(self, frame, i, j, slot=0):
+        idx = np.zeros((self.kcap, 2), np.int32)
+        dist = np.zeros((self.kcap, 2), np.int32)
+        n = C.c_int()
+        _lib.check(self.L.mcorb_rig_get_pair_knn2(self.h_rig, slot, frame, i, j, idx.ctypes.data, dist.ctypes.data,
+                                                  self.kcap, C.byref(n)))
+        return idx[:n.value].copy(), dist[:n.value].copy()
+
+    def tracks(self, frame, slot=0):
+        cap = self.kcap * self.ncams
+        tr = np.full((cap, self.ncams), -1, np.int32)
+        n, mg = C.c_int(), C.c_int()
+        _lib.check(self.L.mcorb_rig_get_tracks(self.h_rig, slot, frame, tr.ctypes.data, cap, C.byref(n), C.byref(mg)))
+        return tr[:n.value].copy(), mg.value
+
+    # -- intermediates (parity tests) -----------------------------------------
+    def level_size(self, level):
+        w, h = C.c_int(), C.c_int()
+        _lib.check(self.L.mcorb_rig_level_size(self.h_rig, level, C.byref(w), C.byref(h)))
+        return w.value, h.value
+
+    def level(self, m, level, slot=0, blurred=False):
+        w, h = self.level_size(level)
+        out = np.zeros((h, w), np.uint8)
+        fn = self.L.mcorb_rig_get_blurred if blurred else self.L.mcorb_rig_get_level
+        _lib.check(fn(self.h_rig, slot, m, level, out.ctypes.data, w))
+        return out
+
+    def candidates(self, m, level, slot=0, cap=1 << 17):
+        buf = np.zeros(cap, np.uint32)
+        n = C.c_int()
+        _lib.check(self.L.mcorb_rig_get_candidates(self.h_rig, slot, m, level, buf.ctypes.data, cap, C.byref(n)))
+        p = buf[:n.value]
+        return ((p >> 8) & 0xfff).astype(np.int32), (p >> 20).astype(np.int32), (p & 0xff).astype(np.int32)
+
+    def timing(self, slot=0):
+        t = (C.c_float * 4)()
+        _lib.check(self.L.mcorb_rig_last_timing(self.h_rig, slot, t))
+        return dict(phase_a_us=t[0], select_us=t[1], phase_b_us=t[2], match_us=t[3])
+
+    def knn2_external(self, desc_dev_ptr, counts, pairs, slot=0):
+        counts = np.ascontiguousarray(counts, np.int32)
+        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        idx = np.zeros((len(pairs), self.kcap, 2), np.int32)
+        dist = np.zeros((len(pairs), self.kcap, 2), np.int32)
+        _lib.check(self.L.mcorb_rig_knn2_external(self.h_rig, slot, desc_dev_ptr, counts.ctypes.data, len(counts),
+                                                  pairs.ctypes.data, len(pairs), idx.ctypes.data, dist.ctypes.data))
+        return idx, dist
+
+
+class ORBextractor:
+    """Mirror of the reference's ORBextractor (ORBextractor.h:43-116) over libmcorb."""
+
+    HARRIS_SCORE, FAST_SCORE = 0, 1
+
+    def __init__(self, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, orientation=ORIENT_NONE, device=0):
+        self.L = _lib.load()
+        self.params = default_params(nfeatures=nfeatures, scale_factor=scaleFactor, nlevels=nlevels,
+                                     ini_th_fast=iniThFAST, min_th_fast=minThFAST, orientation=orientation,
+                                     device_id=device)
+        self._tables = get_tables(self.params)
+        self.max_neighbor_ratio = 0.85   # ORBextractor.h:90
+        h = C.c_void_p()
+        _lib.check(self.L.mcorb_create(C.byref(self.params), 0, 0, C.byref(h)))
+        self.h_ext = h
+
+    def close(self):
+        if getattr(self, "h_ext", None):
+            self.L.mcorb_destroy(self.h_ext)
+            self.h_ext = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __call__(self, image, mask=None, vLappingArea=(0, 0)):
+        """operator() (ORBextractor.cpp:1085-1171): returns (monoIndex, keypoints, descriptors);
+        (-1, None, None) for an empty image, as the reference returns -1.  `mask` is ignored, as in the reference."""
+        if image is None or np.asarray(image).size == 0:
+            return -1, None, None
+        img = np.asarray(image)
+        cap = self.params.nfeatures + 8 * self.params.nlevels + 64
+        kps = np.zeros(cap, KP_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n, mono = C.c_int(), C.c_int()
+        if img.dtype == np.uint8:
+            assert img.ndim == 2, "image.type() == CV_8UC1 (ORBextractor.cpp:1094)"
+            img = _u8(img)
+            st = self.L.mcorb_extract(self.h_ext, img.ctypes.data, img.shape[1], img.shape[0], img.strides[0],
+                                      vLappingArea[0], vLappingArea[1], kps.ctypes.data, desc.ctypes.data, cap,
+                                      C.byref(n), C.byref(mono))
+        else:
+            img = np.ascontiguousarray(img, np.float32)
+            ch = 1 if img.ndim == 2 else img.shape[2]
+            st = self.L.mcorb_extract_f32(self.h_ext, img.ctypes.data, img.shape[1], img.shape[0], img.strides[0], ch,
+                                          vLappingArea[0], vLappingArea[1], kps.ctypes.data, desc.ctypes.data, cap,
+                                          C.byref(n), C.byref(mono))
+        if st == E_EMPTY:
+            return -1, None, None
+        _lib.check(st)
+        return mono.value, kps[:n.value].copy(), desc[:n.value].copy()
+
+    def pyramid_level(self, level):
+        """mvImagePyramid[level] (interior) of the last call (ORBextractor.h:89)."""
+        w, h = C.c_int(), C.c_int()
+        _lib.check(self.L.mcorb_get_pyramid_level(self.h_ext, level, None, 0, C.byref(w), C.byref(h)))
+        out = np.zeros((h.value, w.value), np.uint8)
+        _lib.check(self.L.mcorb_get_pyramid_level(self.h_ext, level, out.ctypes.data, w.value, C.byref(w), C.byref(h)))
+        return out
+
+    def GetLevels(self):
+        return self.params.nlevels
+
+    def GetScaleFactor(self):
+        return float(np.float32(self.params.scale_factor))
+
+    def GetScaleFactors(self):
+        return self._tables["scale"].copy()
+
+    def GetInverseScaleFactors(self):
+        return self._tables["inv_scale"].copy()
+
+    def GetScaleSigmaSquares(self):
+        return self._tables["sigma2"].copy()
+
+    def GetInverseScaleSigmaSquares(self):
+        return self._tables["inv_sigma2"].copy()
+
+    def DescriptorDistance(self, a, b):
+        return hamming256(a, b)
+
+    def knnMatch2(self, q, t):
+        """DescriptorMatcher("BruteForce-Hamming")->knnMatch(q, t, out, 2) on the GPU."""
+        q, t = _u8(q).reshape(-1, 32), _u8(t).reshape(-1, 32)
+        idx = np.zeros((len(q), 2), np.int32)
+        dist = np.zeros((len(q), 2), np.int32)
+        _lib.check(self.L.mcorb_knn2(self.h_ext, q.ctypes.data, len(q), t.ctypes.data, len(t), idx.ctypes.data,
+                                     dist.ctypes.data))
+        return idx, dist
+
+    def matchRatio(self, q, t, dist_thresh=75.0, ratio=0.85):
+        """BruteForceMatch's knn2 + ratio/threshold filter (MultiCameraFrame.cpp:1053-1078)."""
+        q, t = _u8(q).reshape(-1, 32), _u8(t).reshape(-1, 32)
+        i1 = np.zeros(len(q) + 1, np.uint32)
+        i2 = np.zeros(len(q) + 1, np.uint32)
+        n = C.c_int()
+        _lib.check(self.L.mcorb_match_ratio(self.h_ext, q.ctypes.data, len(q), t.ctypes.data, len(t), dist_thresh,
+                                            ratio, i1.ctypes.data, i2.ctypes.data, len(q), C.byref(n)))
+        return i1[:n.value].copy(), i2[:n.value].copy()
+
+    def getMatches_distRatio(self, A, i_A, B, i_B):
+        """ORBextractor::getMatches_distRatio (ORBextractor.cpp:1228-1290): best / second-best search on the
+        GPU k-NN kernel, the reference's one-to-one bookkeeping on the host.  Returns (i_match_A, i_match_B, BookK)."""
+        A, B = _u8(A).reshape(-1, 32), _u8(B).reshape(-1, 32)
+        i_A, i_B = np.asarray(i_A, np.int64), np.asarray(i_B, np.int64)
+        mA, mB = [], []
+        book = len(i_A) * len(i_B)
+        if len(i_A) == 0 or len(i_B) == 0:
+            return np.zeros(0, np.uint32), np.zeros(0, np.uint32), book
+        idx, dist = self.knnMatch2(A[i_A], B[i_B])
+        for a in range(len(i_A)):
+            d1 = float(dist[a, 0])
+            d2 = float(dist[a, 1]) if idx[a, 1] >= 0 else 1e9
+            if d1 <= TH_LOW and d1 / d2 <= self.max_neighbor_ratio:
+                idx_B = int(i_B[idx[a, 0]])
+                if idx_B not in mB:
+                    mB.append(idx_B)
+                    mA.append(int(i_A[a]))
+                else:
+                    k = mB.index(idx_B)
+                    d = hamming256(A[mA[k]], B[idx_B])
+                    book += 1
+                    if d1 < d:
+                        mA[k] = int(i_A[a])
+        return np.array(mA, np.uint32), np.array(mB, np.uint32), book
+
+
+class IntraMatch:
+    """MultiCameraFrame.h:42-57 (matchIndex widened from 5 to ncams entries)."""
+
+    def __init__(self, matchIndex):
+        self.matchIndex = list(matchIndex)
+        self.mono = True
+        self.n_rays = 0
+
+
+class MultiCameraFrame:
+    """Mirror of the extract + intra-rig-match members of MultiCameraFrame
+    (MultiCameraFrame.h:70-90) for one rig frame."""
+
+    def __init__(self, ncams, width, height, params=None, rig=None, **kw):
+        self.num_cams_ = ncams
+        self.rig = rig if rig is not None else Rig(ncams, width, height, 1, 1, params=params, **kw)
+        self.imgs = []
+        self.image_kps, self.image_kps_undist, self.image_descriptors = [], [], []
+        self._matched = False
+
+    def setData(self, img_set, segmap_set=None):
+        """setData (MultiCameraFrame.cpp:95-152): accepts the reference's CV_32F [0,1] frames or u8."""
+        if len(img_set) != self.num_cams_:
+            print("ERROR:: number of images is wrong")   # the reference prints and returns (:98-101)
+            return
+        self.imgs = list(img_set)
+        self.rig.upload(self.imgs)
+        self._matched = False
+
+    def extractFeaturesParallel(self):
+        """extractFeaturesParallel (MultiCameraFrame.cpp:203-228)."""
+        assert self.num_cams_ == len(self.imgs)
+        self.rig.extract(self.num_cams_)
+        self.image_kps, self.image_descriptors = [], []
+        for c in range(self.num_cams_):
+            _, k, d = self.rig.features(c)
+            self.image_kps.append(k)
+            self.image_descriptors.append(d)
+        self.image_kps_undist = self.image_kps   # RECTIFY=false, zero distortion branch (:302-305)
+        self._matched = False
+
+    extractFeatures = extractFeaturesParallel
+
+    def _ensure_match(self, dist_thresh, ratio):
+        key = (float(dist_thresh), float(ratio))
+        if self._matched != key:
+            self.rig.match(1, dist_thresh=dist_thresh, ratio=ratio)
+            self._matched = key
+
+    def BruteForceMatch(self, img1_ind, img2_ind, dist_thresh, neigh_ratio):
+        """BruteForceMatch (MultiCameraFrame.cpp:1024-1086): returns indices_1, indices_2, kps1, kps2."""
+        if not img1_ind < img2_ind:
+            raise ValueError("the reference calls BruteForceMatch with cam1 < cam2 only")
+        self._ensure_match(dist_thresh, neigh_ratio)
+        i1, i2 = self.rig.pair_matches(0, img1_ind, img2_ind)
+        return i1, i2, self.image_kps_undist[img1_ind][i1], self.image_kps_undist[img2_ind][i2]
+
+    def computeIntraMatches(self, old=False, dist_thresh=75.0, ratio=0.85):
+        """computeIntraMatches(matches, old=false) (MultiCameraFrame.cpp:1100-1288)."""
+        if old:
+            raise NotImplementedError("epipolar gate needs rig calibration; the live call site passes false")
+        self._ensure_match(dist_thresh, ratio)
+        tr, mergeable = self.rig.tracks(0)
+        self.cnt_mergable_matches = mergeable
+        return [IntraMatch(row) for row in tr]

@@ -1,0 +1,115 @@
+"""ctypes declarations for libmcorb.so (include/mcorb.h).
+
+The library is the product: HIP kernels + host engine behind a C ABI.  There is
+no Python or CPU fallback -- if the shared object is missing this module raises,
+and if no gfx950 device is usable the C calls return MCORB_E_NODEVICE.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libmcorb.so")
+
+OK, E_EMPTY, E_SIZE, E_CAP, E_ARG, E_HIP, E_NODEVICE, E_STATE, E_OVERFLOW = 0, -1, -2, -3, -4, -5, -6, -7, -8
+ORIENT_NONE, ORIENT_IC_ANGLE = 0, 1
+MAX_LEVELS, MAX_CAMS = 16, 16
+
+KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+
+
+class Params(C.Structure):
+    _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
+                ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("orientation", C.c_int),
+                ("device_id", C.c_int), ("host_threads", C.c_int), ("cand_cap", C.c_int),
+                ("reserved", C.c_int * 7)]
+
+
+class McorbError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("mcorb error %d: %s" % (code, msg))
+        self.code = code
+
+
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+_ip = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); every symbol include/mcorb.h declares
+SIGNATURES = {
+    "mcorb_default_params": (None, [C.POINTER(Params)]),
+    "mcorb_last_error": (C.c_char_p, []),
+    "mcorb_version": (C.c_char_p, []),
+    "mcorb_device_count": (_i, []),
+    "mcorb_rig_create": (_i, [C.POINTER(Params), _i, _i, _i, _i, _i, C.POINTER(_vp)]),
+    "mcorb_rig_destroy": (None, [_vp]),
+    "mcorb_rig_upload_u8": (_i, [_vp, _i, C.POINTER(_vp), _i, _i]),
+    "mcorb_rig_upload_f32": (_i, [_vp, _i, C.POINTER(_vp), _i, _i, _i]),
+    "mcorb_rig_extract_submit": (_i, [_vp, _i, _i, _i, _i]),
+    "mcorb_rig_extract_wait": (_i, [_vp, _i]),
+    "mcorb_rig_extract": (_i, [_vp, _i, _i, _i, _i]),
+    "mcorb_rig_process_submit": (_i, [_vp, _i, _i, _i, _i, _f, _f]),
+    "mcorb_rig_process_wait": (_i, [_vp, _i]),
+    "mcorb_rig_num_keypoints": (_i, [_vp, _i, _i]),
+    "mcorb_rig_get_features": (_i, [_vp, _i, _i, _vp, _vp, _i, _ip, _ip]),
+    "mcorb_rig_match": (_i, [_vp, _i, _i, _f, _f]),
+    "mcorb_rig_match_submit": (_i, [_vp, _i, _i, _f, _f]),
+    "mcorb_rig_match_wait": (_i, [_vp, _i]),
+    "mcorb_rig_get_pair_matches": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _ip]),
+    "mcorb_rig_get_pair_knn2": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _ip]),
+    "mcorb_rig_get_tracks": (_i, [_vp, _i, _i, _vp, _i, _ip, _ip]),
+    "mcorb_rig_level_size": (_i, [_vp, _i, _ip, _ip]),
+    "mcorb_rig_get_level": (_i, [_vp, _i, _i, _i, _vp, _i]),
+    "mcorb_rig_get_blurred": (_i, [_vp, _i, _i, _i, _vp, _i]),
+    "mcorb_rig_get_candidates": (_i, [_vp, _i, _i, _i, _vp, _i, _ip]),
+    "mcorb_rig_last_timing": (_i, [_vp, _i, C.POINTER(_f)]),
+    "mcorb_rig_kcap": (_i, [_vp]),
+    "mcorb_rig_desc_device_ptr": (_vp, [_vp, _i]),
+    "mcorb_rig_stream": (_vp, [_vp, _i]),
+    "mcorb_rig_knn2_external": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "mcorb_create": (_i, [C.POINTER(Params), _i, _i, C.POINTER(_vp)]),
+    "mcorb_destroy": (None, [_vp]),
+    "mcorb_extract": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _ip, _ip]),
+    "mcorb_extract_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _ip, _ip]),
+    "mcorb_get_tables": (_i, [C.POINTER(Params), _vp, _vp, _vp, _vp, _vp]),
+    "mcorb_get_pyramid_level": (_i, [_vp, _i, _vp, _i, _ip, _ip]),
+    "mcorb_hamming256": (_i, [_vp, _vp]),
+    "mcorb_knn2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "mcorb_match_ratio": (_i, [_vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _i, _ip]),
+    "mcorb_synth_rig_frame": (_i, [C.c_uint32, _i, _i, _i, _i, _vp, _i]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmcorb.so; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libmcorb.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` or `make -C mc-slam_amd/csrc` (hipcc, gfx950). There is no CPU fallback."
+                          % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)   # AttributeError here means the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != OK:
+        raise McorbError(code, load().mcorb_last_error().decode("utf-8", "replace"))
+    return code
+
+
+def default_params(**kw):
+    p = Params()
+    load().mcorb_default_params(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p

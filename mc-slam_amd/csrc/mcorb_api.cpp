@@ -1,0 +1,542 @@
+// mcorb_api.cpp -- extern "C" entry points of libmcorb (include/mcorb.h).
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+
+#include "mcorb_engine.h"
+
+using namespace mcorb;
+
+struct mcorb_rig {
+    Rig rig;
+};
+
+struct mcorb_extractor {
+    mcorb_params params;
+    Rig *rig = nullptr;   // rebuilt when the image size changes
+    int w = 0, h = 0;
+    // scratch for mcorb_knn2 on host arrays
+    uint8_t *d_desc = nullptr;
+    uint2 *d_part = nullptr;
+    KnnRow *h_rows = nullptr;
+    int *h_counts = nullptr;
+    int2 *h_pair = nullptr;
+    int kc = 0;
+};
+
+#define HIPCHK(x)                                                                      \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            set_error(std::string(#x) + ": " + hipGetErrorString(e_));                 \
+            return MCORB_E_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+extern "C" {
+
+void mcorb_default_params(mcorb_params *p)
+{
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->nfeatures = 2000;
+    p->scale_factor = 1.2f;
+    p->nlevels = 8;
+    p->ini_th_fast = 20;
+    p->min_th_fast = 7;
+    p->orientation = MCORB_ORIENT_NONE;
+}
+
+const char *mcorb_last_error(void) { return get_error(); }
+const char *mcorb_version(void) { return "mcorb 0.1 (gfx950)"; }
+
+int mcorb_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    int ok = 0;
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) == 0) ok++;
+    }
+    return ok;
+}
+
+// ---------------------------------------------------------------------------
+// rig
+// ---------------------------------------------------------------------------
+int mcorb_rig_create(const mcorb_params *p, int ncams, int width, int height, int max_frames, int nslots,
+                     mcorb_rig **out)
+{
+    if (!p || !out) { set_error("null argument"); return MCORB_E_ARG; }
+    *out = nullptr;
+    mcorb_rig *r = new (std::nothrow) mcorb_rig;
+    if (!r) { set_error("out of memory"); return MCORB_E_ARG; }
+    const int st = r->rig.init(*p, ncams, width, height, max_frames, nslots);
+    if (st != MCORB_OK) {
+        const std::string keep = get_error();
+        delete r;
+        set_error(keep);
+        return st;
+    }
+    *out = r;
+    return MCORB_OK;
+}
+
+void mcorb_rig_destroy(mcorb_rig *r) { delete r; }
+
+int mcorb_rig_upload_u8(mcorb_rig *r, int slot, const uint8_t *const *images, int nimg, int stride)
+{
+    if (!r) return MCORB_E_ARG;
+    return r->rig.upload_u8(slot, images, nimg, stride);
+}
+int mcorb_rig_upload_f32(mcorb_rig *r, int slot, const float *const *images, int nimg, int stride_bytes, int channels)
+{
+    if (!r) return MCORB_E_ARG;
+    return r->rig.upload_f32(slot, images, nimg, stride_bytes, channels);
+}
+
+int mcorb_rig_extract_submit(mcorb_rig *r, int slot, int nimg, int lap_x0, int lap_x1)
+{
+    if (!r) return MCORB_E_ARG;
+    Job j;
+    j.kind = Job::EXTRACT; j.nimg = nimg; j.lap0 = lap_x0; j.lap1 = lap_x1;
+    return r->rig.submit(slot, j);
+}
+int mcorb_rig_extract_wait(mcorb_rig *r, int slot) { return r ? r->rig.wait(slot) : MCORB_E_ARG; }
+int mcorb_rig_extract(mcorb_rig *r, int slot, int nimg, int lap_x0, int lap_x1)
+{
+    const int st = mcorb_rig_extract_submit(r, slot, nimg, lap_x0, lap_x1);
+    return st != MCORB_OK ? st : mcorb_rig_extract_wait(r, slot);
+}
+
+int mcorb_rig_process_submit(mcorb_rig *r, int slot, int nframes, int lap_x0, int lap_x1, float dist_thresh, float ratio)
+{
+    if (!r) return MCORB_E_ARG;
+    Job j;
+    j.kind = Job::PROCESS; j.nframes = nframes; j.nimg = nframes * r->rig.ncams; j.lap0 = lap_x0; j.lap1 = lap_x1;
+    j.dist_thresh = dist_thresh; j.ratio = ratio;
+    return r->rig.submit(slot, j);
+}
+int mcorb_rig_process_wait(mcorb_rig *r, int slot) { return r ? r->rig.wait(slot) : MCORB_E_ARG; }
+
+int mcorb_rig_match_submit(mcorb_rig *r, int slot, int nframes, float dist_thresh, float ratio)
+{
+    if (!r) return MCORB_E_ARG;
+    Job j;
+    j.kind = Job::MATCH; j.nframes = nframes; j.dist_thresh = dist_thresh; j.ratio = ratio;
+    return r->rig.submit(slot, j);
+}
+int mcorb_rig_match_wait(mcorb_rig *r, int slot) { return r ? r->rig.wait(slot) : MCORB_E_ARG; }
+int mcorb_rig_match(mcorb_rig *r, int slot, int nframes, float dist_thresh, float ratio)
+{
+    const int st = mcorb_rig_match_submit(r, slot, nframes, dist_thresh, ratio);
+    return st != MCORB_OK ? st : mcorb_rig_match_wait(r, slot);
+}
+
+static Slot *get_slot(mcorb_rig *r, int slot)
+{
+    if (!r || slot < 0 || slot >= (int)r->rig.slots.size()) { set_error("bad rig/slot"); return nullptr; }
+    Slot *s = r->rig.slots[slot];
+    std::lock_guard<std::mutex> lk(s->m);
+    if (s->busy) { set_error("slot busy"); return nullptr; }
+    return s;
+}
+
+int mcorb_rig_num_keypoints(mcorb_rig *r, int slot, int m)
+{
+    Slot *s = get_slot(r, slot);
+    if (!s) return MCORB_E_STATE;
+    if (m < 0 || m >= s->nimg_done) { set_error("image index out of range"); return MCORB_E_ARG; }
+    return (int)s->kps[m].size();
+}
+
+int mcorb_rig_get_features(mcorb_rig *r, int slot, int m, mcorb_keypoint *kps, uint8_t *desc, int cap, int *n_out,
+                           int *mono_index_out)
+{
+    Slot *s = get_slot(r, slot);
+    if (!s) return MCORB_E_STATE;
+    if (m < 0 || m >= s->nimg_done) { set_error("image index out of range"); return MCORB_E_ARG; }
+    const int n = (int)s->kps[m].size();
+    if (n_out) *n_out = n;
+    if (mono_index_out) *mono_index_out = s->mono[m];
+    if (n > cap) { set_error("keypoint buffer too small"); return MCORB_E_CAP; }
+    if (kps && n) memcpy(kps, s->kps[m].data(), (size_t)n * sizeof(mcorb_keypoint));
+    if (desc && n) memcpy(desc, s->h_desc + (size_t)m * r->rig.geom.kcap * 32, (size_t)n * 32);
+    return MCORB_OK;
+}
+
+static int pair_index(const Rig &R, int frame, int a, int b)
+{
+    if (a < 0 || b <= a || b >= R.ncams) return -1;
+    int pi = 0;
+    for (int i = 0; i < a; i++) pi += R.ncams - 1 - i;
+    pi += b - a - 1;
+    return frame * R.npp + pi;
+}
+
+int mcorb_rig_get_pair_matches(mcorb_rig *r, int slot, int frame, int cam_i, int cam_j, uint32_t *idx1, uint32_t *idx2,
+                               int cap, int *n_out)
+{
+    Slot *s = get_slot(r, slot);
+    if (!s) return MCORB_E_STATE;
+    const int pi = pair_index(r->rig, frame, cam_i, cam_j);
+    if (frame < 0 || frame >= s->nframes_done || pi < 0) { set_error("bad frame/pair"); return MCORB_E_ARG; }
+    const int n = (int)s->m_idx1[pi].size();
+    if (n_out) *n_out = n;
+    if (n > cap) { set_error("match buffer too small"); return MCORB_E_CAP; }
+    if (n) {
+        memcpy(idx1, s->m_idx1[pi].data(), (size_t)n * 4);
+        memcpy(idx2, s->m_idx2[pi].data(), (size_t)n * 4);
+    }
+    return MCORB_OK;
+}
+
+static void decode_rows(const KnnRow *rows, int nq, int32_t *idx, int32_t *dist)
+{
+    for (int q = 0; q < nq; q++) {
+        const KnnRow &k = rows[q];
+        idx[2 * q] = k.idx0;
+        dist[2 * q] = k.d0;
+        idx[2 * q + 1] = k.idx1;
+        dist[2 * q + 1] = k.idx1 < 0 ? -1 : (k.d1 & 0x3fffffff);
+    }
+}
+
+int mcorb_rig_get_pair_knn2(mcorb_rig *r, int slot, int frame, int cam_i, int cam_j, int32_t *idx, int32_t *dist,
+                            int cap_rows, int *nq_out)
+{
+    Slot *s = get_slot(r, slot);
+    if (!s) return MCORB_E_STATE;
+    const int pi = pair_index(r->rig, frame, cam_i, cam_j);
+    if (frame < 0 || frame >= s->nframes_done || pi < 0) { set_error("bad frame/pair"); return MCORB_E_ARG; }
+    const int nq = s->h_nsel[frame * r->rig.ncams + cam_i];
+    if (nq_out) *nq_out = nq;
+    if (nq > cap_rows) { set_error("knn buffer too small"); return MCORB_E_CAP; }
+    decode_rows(s->h_knn + (size_t)pi * r->rig.geom.kcap, nq, idx, dist);
+    return MCORB_OK;
+}
+
+int mcorb_rig_get_tracks(mcorb_rig *r, int slot, int frame, int32_t *tracks, int cap_tracks, int *ntracks_out,
+                         int *mergeable_out)
+{
+    Slot *s = get_slot(r, slot);
+    if (!s) return MCORB_E_STATE;
+    if (frame < 0 || frame >= s->nframes_done) { set_error("bad frame"); return MCORB_E_ARG; }
+    const int C = r->rig.ncams;
+    const int n = (int)(s->tracks[frame].size() / C);
+    if (ntracks_out) *ntracks_out = n;
+    if (mergeable_out) *mergeable_out = s->mergeable[frame];
+    if (n > cap_tracks) { set_error("track buffer too small"); return MCORB_E_CAP; }
+    if (n) memcpy(tracks, s->tracks[frame].data(), (size_t)n * C * 4);
+    return MCORB_OK;
+}
+
+int mcorb_rig_level_size(mcorb_rig *r, int level, int *w, int *h)
+{
+    if (!r || level < 0 || level >= r->rig.geom.nlevels) return MCORB_E_ARG;
+    if (w) *w = r->rig.geom.lv[level].w;
+    if (h) *h = r->rig.geom.lv[level].h;
+    return MCORB_OK;
+}
+
+static int copy_plane(mcorb_rig *r, int slot, int m, int level, bool blurred, uint8_t *dst, int dst_stride)
+{
+    Slot *s = get_slot(r, slot);
+    if (!s) return MCORB_E_STATE;
+    const Geom &g = r->rig.geom;
+    if (m < 0 || m >= r->rig.max_images || level < 0 || level >= g.nlevels || !dst || dst_stride < g.lv[level].w) {
+        set_error("bad plane request");
+        return MCORB_E_ARG;
+    }
+    HIPCHK(hipSetDevice(r->rig.device));
+    HIPCHK(hipStreamSynchronize(s->st));
+    const uint8_t *src = (blurred ? s->d_blur : s->d_pyr) + (size_t)m * g.imgBytes + g.lv[level].off;
+    HIPCHK(hipMemcpy2D(dst, dst_stride, src, g.lv[level].pitch, g.lv[level].w, g.lv[level].h, hipMemcpyDeviceToHost));
+    return MCORB_OK;
+}
+int mcorb_rig_get_level(mcorb_rig *r, int slot, int m, int level, uint8_t *dst, int dst_stride)
+{
+    return copy_plane(r, slot, m, level, false, dst, dst_stride);
+}
+int mcorb_rig_get_blurred(mcorb_rig *r, int slot, int m, int level, uint8_t *dst, int dst_stride)
+{
+    return copy_plane(r, slot, m, level, true, dst, dst_stride);
+}
+
+int mcorb_rig_get_candidates(mcorb_rig *r, int slot, int m, int level, uint32_t *packed, int cap, int *n_out)
+{
+    Slot *s = get_slot(r, slot);
+    if (!s) return MCORB_E_STATE;
+    const Geom &g = r->rig.geom;
+    if (m < 0 || m >= s->nimg_done || level < 0 || level >= g.nlevels) { set_error("bad candidate request"); return MCORB_E_ARG; }
+    const int *lo = s->h_lvloff + (size_t)m * (kMaxLevels + 1);
+    const int n = lo[level + 1] - lo[level];
+    if (n_out) *n_out = n;
+    if (n > cap) { set_error("candidate buffer too small"); return MCORB_E_CAP; }
+    if (n) memcpy(packed, s->h_cand + (size_t)m * g.candCap + lo[level], (size_t)n * 4);
+    return MCORB_OK;
+}
+
+int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[4])
+{
+    Slot *s = get_slot(r, slot);
+    if (!s) return MCORB_E_STATE;
+    for (int i = 0; i < 4; i++) us[i] = s->timing[i];
+    return MCORB_OK;
+}
+
+int mcorb_rig_kcap(mcorb_rig *r) { return r ? r->rig.geom.kcap : MCORB_E_ARG; }
+void *mcorb_rig_desc_device_ptr(mcorb_rig *r, int slot)
+{
+    if (!r || slot < 0 || slot >= (int)r->rig.slots.size()) return nullptr;
+    return r->rig.slots[slot]->d_desc;
+}
+void *mcorb_rig_stream(mcorb_rig *r, int slot)
+{
+    if (!r || slot < 0 || slot >= (int)r->rig.slots.size()) return nullptr;
+    return (void *)r->rig.slots[slot]->st;
+}
+
+int mcorb_rig_knn2_external(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts, int ntotal,
+                            const int32_t *pairs_qt, int npairs, int32_t *idx, int32_t *dist)
+{
+    if (!r || !desc_dev || !counts || !pairs_qt || !idx || !dist) { set_error("null argument"); return MCORB_E_ARG; }
+    Job j;
+    j.kind = Job::MATCH;
+    j.ext_desc = desc_dev; j.ext_counts = counts; j.ext_total = ntotal; j.ext_pairs = pairs_qt; j.ext_npairs = npairs;
+    int st = r->rig.submit(slot, j);
+    if (st != MCORB_OK) return st;
+    st = r->rig.wait(slot);
+    if (st != MCORB_OK) return st;
+    Slot *s = r->rig.slots[slot];
+    const int kcap = r->rig.geom.kcap;
+    for (int p = 0; p < npairs; p++) {
+        const int nq = counts[pairs_qt[2 * p]];
+        for (int q = 0; q < kcap; q++) { idx[((size_t)p * kcap + q) * 2] = idx[((size_t)p * kcap + q) * 2 + 1] = -1;
+                                         dist[((size_t)p * kcap + q) * 2] = dist[((size_t)p * kcap + q) * 2 + 1] = -1; }
+        decode_rows(s->h_knn + (size_t)p * kcap, std::min(nq, kcap), idx + (size_t)p * kcap * 2, dist + (size_t)p * kcap * 2);
+    }
+    return MCORB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// single-camera extractor
+// ---------------------------------------------------------------------------
+int mcorb_create(const mcorb_params *p, int max_width, int max_height, mcorb_t **out)
+{
+    if (!p || !out) { set_error("null argument"); return MCORB_E_ARG; }
+    *out = nullptr;
+    Tables t;
+    int st = compute_tables(*p, t);
+    if (st != MCORB_OK) return st;
+    mcorb_t *e = new (std::nothrow) mcorb_extractor;
+    if (!e) return MCORB_E_ARG;
+    e->params = *p;
+    if (max_width > 0 && max_height > 0) {
+        e->rig = new Rig;
+        st = e->rig->init(*p, 1, max_width, max_height, 1, 1);
+        if (st != MCORB_OK) {
+            const std::string keep = get_error();
+            delete e->rig;
+            delete e;
+            set_error(keep);
+            return st;
+        }
+        e->w = max_width; e->h = max_height;
+    } else if (mcorb_device_count() < 1) {
+        delete e;
+        set_error("no usable gfx950 device (libmcorb has no CPU path)");
+        return MCORB_E_NODEVICE;
+    }
+    *out = e;
+    return MCORB_OK;
+}
+
+static void free_knn_scratch(mcorb_t *e)
+{
+    if (e->d_desc) (void)hipFree(e->d_desc);
+    if (e->d_part) (void)hipFree(e->d_part);
+    if (e->h_rows) (void)hipHostFree(e->h_rows);
+    if (e->h_counts) (void)hipHostFree(e->h_counts);
+    if (e->h_pair) (void)hipHostFree(e->h_pair);
+    e->d_desc = nullptr; e->d_part = nullptr; e->h_rows = nullptr; e->h_counts = nullptr; e->h_pair = nullptr;
+    e->kc = 0;
+}
+
+void mcorb_destroy(mcorb_t *e)
+{
+    if (!e) return;
+    free_knn_scratch(e);
+    delete e->rig;
+    delete e;
+}
+
+static int ensure_rig(mcorb_t *e, int w, int h)
+{
+    if (e->rig && e->w == w && e->h == h) return MCORB_OK;
+    delete e->rig;
+    e->rig = new Rig;
+    const int st = e->rig->init(e->params, 1, w, h, 1, 1);
+    if (st != MCORB_OK) {
+        const std::string keep = get_error();
+        delete e->rig;
+        e->rig = nullptr;
+        set_error(keep);
+        return st;
+    }
+    e->w = w; e->h = h;
+    return MCORB_OK;
+}
+
+static int finish_extract(mcorb_t *e, int lap_x0, int lap_x1, mcorb_keypoint *kps, uint8_t *desc, int cap, int *n_out,
+                          int *mono_index_out)
+{
+    Job j;
+    j.kind = Job::EXTRACT; j.nimg = 1; j.lap0 = lap_x0; j.lap1 = lap_x1;
+    int st = e->rig->submit(0, j);
+    if (st == MCORB_OK) st = e->rig->wait(0);
+    if (st != MCORB_OK) return st;
+    Slot *s = e->rig->slots[0];
+    const int n = (int)s->kps[0].size();
+    if (n_out) *n_out = n;
+    if (mono_index_out) *mono_index_out = s->mono[0];
+    if (n > cap) { set_error("keypoint buffer too small"); return MCORB_E_CAP; }
+    if (kps && n) memcpy(kps, s->kps[0].data(), (size_t)n * sizeof(mcorb_keypoint));
+    if (desc && n) memcpy(desc, s->h_desc, (size_t)n * 32);
+    return MCORB_OK;
+}
+
+int mcorb_extract(mcorb_t *e, const uint8_t *gray, int w, int h, int stride_bytes, int lap_x0, int lap_x1,
+                  mcorb_keypoint *kps, uint8_t *desc, int cap, int *n_out, int *mono_index_out)
+{
+    if (!e) { set_error("null extractor"); return MCORB_E_ARG; }
+    if (n_out) *n_out = 0;
+    if (!gray || w <= 0 || h <= 0) { set_error("empty image"); return MCORB_E_EMPTY; }
+    int st = ensure_rig(e, w, h);
+    if (st != MCORB_OK) return st;
+    const uint8_t *imgs[1] = {gray};
+    st = e->rig->upload_u8(0, imgs, 1, stride_bytes);
+    if (st != MCORB_OK) return st;
+    return finish_extract(e, lap_x0, lap_x1, kps, desc, cap, n_out, mono_index_out);
+}
+
+int mcorb_extract_f32(mcorb_t *e, const float *img01, int w, int h, int stride_bytes, int channels, int lap_x0,
+                      int lap_x1, mcorb_keypoint *kps, uint8_t *desc, int cap, int *n_out, int *mono_index_out)
+{
+    if (!e) { set_error("null extractor"); return MCORB_E_ARG; }
+    if (n_out) *n_out = 0;
+    if (!img01 || w <= 0 || h <= 0) { set_error("empty image"); return MCORB_E_EMPTY; }
+    int st = ensure_rig(e, w, h);
+    if (st != MCORB_OK) return st;
+    const float *imgs[1] = {img01};
+    st = e->rig->upload_f32(0, imgs, 1, stride_bytes, channels);
+    if (st != MCORB_OK) return st;
+    return finish_extract(e, lap_x0, lap_x1, kps, desc, cap, n_out, mono_index_out);
+}
+
+int mcorb_get_tables(const mcorb_params *p, float *scale, float *inv_scale, float *sigma2, float *inv_sigma2,
+                     int *features_per_level)
+{
+    if (!p) return MCORB_E_ARG;
+    Tables t;
+    const int st = compute_tables(*p, t);
+    if (st != MCORB_OK) return st;
+    for (int i = 0; i < t.nlevels; i++) {
+        if (scale) scale[i] = t.scale[i];
+        if (inv_scale) inv_scale[i] = t.inv_scale[i];
+        if (sigma2) sigma2[i] = t.sigma2[i];
+        if (inv_sigma2) inv_sigma2[i] = t.inv_sigma2[i];
+        if (features_per_level) features_per_level[i] = t.quota[i];
+    }
+    return MCORB_OK;
+}
+
+int mcorb_get_pyramid_level(mcorb_t *e, int level, uint8_t *dst, int dst_stride, int *w, int *h)
+{
+    if (!e || !e->rig) { set_error("no image processed yet"); return MCORB_E_STATE; }
+    const Geom &g = e->rig->geom;
+    if (level < 0 || level >= g.nlevels) return MCORB_E_ARG;
+    if (w) *w = g.lv[level].w;
+    if (h) *h = g.lv[level].h;
+    if (!dst) return MCORB_OK;
+    if (dst_stride < g.lv[level].w) return MCORB_E_ARG;
+    Slot *s = e->rig->slots[0];
+    HIPCHK(hipSetDevice(e->rig->device));
+    HIPCHK(hipStreamSynchronize(s->st));
+    HIPCHK(hipMemcpy2D(dst, dst_stride, s->d_pyr + g.lv[level].off, g.lv[level].pitch, g.lv[level].w, g.lv[level].h,
+                       hipMemcpyDeviceToHost));
+    return MCORB_OK;
+}
+
+// ORBextractor::DescriptorDistance (ORBextractor.cpp:1202-1218)
+int mcorb_hamming256(const uint8_t a[32], const uint8_t b[32])
+{
+    uint64_t x[4], y[4];
+    memcpy(x, a, 32);
+    memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) + __builtin_popcountll(x[2] ^ y[2]) +
+           __builtin_popcountll(x[3] ^ y[3]);
+}
+
+static int knn2_host_arrays(mcorb_t *e, const uint8_t *q, int nq, const uint8_t *t, int nt, float thr, float ratio)
+{
+    if (!e || nq < 0 || nt < 0 || (nq && !q) || (nt && !t)) { set_error("knn2: bad argument"); return MCORB_E_ARG; }
+    if (nq > 65535 || nt > 65535) { set_error("knn2: more than 65535 descriptors"); return MCORB_E_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || e->params.device_id >= ndev) {
+        set_error("no usable HIP device (libmcorb has no CPU path)");
+        return MCORB_E_NODEVICE;
+    }
+    HIPCHK(hipSetDevice(e->params.device_id));
+    const int need = (std::max(std::max(nq, nt), 1) + 63) / 64 * 64;
+    if (need > e->kc) {
+        free_knn_scratch(e);
+        const int nchunks = (need + kKnnChunk - 1) / kKnnChunk;
+        HIPCHK(hipMalloc((void **)&e->d_desc, (size_t)2 * need * 32));
+        HIPCHK(hipMalloc((void **)&e->d_part, (size_t)nchunks * need * sizeof(uint2)));
+        HIPCHK(hipHostMalloc((void **)&e->h_rows, (size_t)need * sizeof(KnnRow), hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void **)&e->h_counts, 2 * sizeof(int), hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void **)&e->h_pair, sizeof(int2), hipHostMallocMapped));
+        e->kc = need;
+    }
+    if (nq) HIPCHK(hipMemcpy(e->d_desc, q, (size_t)nq * 32, hipMemcpyHostToDevice));
+    if (nt) HIPCHK(hipMemcpy(e->d_desc + (size_t)e->kc * 32, t, (size_t)nt * 32, hipMemcpyHostToDevice));
+    e->h_counts[0] = nq;
+    e->h_counts[1] = nt;
+    e->h_pair[0] = int2{0, 1};
+    launch_knn2(nullptr, e->d_desc, e->h_counts, e->h_pair, 1, e->kc, e->d_part, thr, ratio, e->h_rows);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return MCORB_OK;
+}
+
+int mcorb_knn2(mcorb_t *e, const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist)
+{
+    if (!idx || !dist) { set_error("null output"); return MCORB_E_ARG; }
+    const int st = knn2_host_arrays(e, q, nq, t, nt, 75.f, 0.85f);
+    if (st != MCORB_OK) return st;
+    decode_rows(e->h_rows, nq, idx, dist);
+    return MCORB_OK;
+}
+
+int mcorb_match_ratio(mcorb_t *e, const uint8_t *q, int nq, const uint8_t *t, int nt, float dist_thresh, float ratio,
+                      uint32_t *idx1, uint32_t *idx2, int cap, int *n_out)
+{
+    const int st = knn2_host_arrays(e, q, nq, t, nt, dist_thresh, ratio);
+    if (st != MCORB_OK) return st;
+    int n = 0;
+    for (int i = 0; i < nq; i++) {
+        const KnnRow &r = e->h_rows[i];
+        if (r.idx1 >= 0 && ((r.d1 >> 30) & 1)) {
+            if (n < cap) { idx1[n] = (uint32_t)i; idx2[n] = (uint32_t)r.idx0; }
+            n++;
+        }
+    }
+    if (n_out) *n_out = n;
+    if (n > cap) { set_error("match buffer too small"); return MCORB_E_CAP; }
+    return MCORB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,690 @@
+// mcorb_engine.cpp -- host orchestration: tables, geometry, buffers, slot drivers.
+//
+// Data flow of one batch (nimg equally sized images, all resident in HBM):
+//   phase A (GPU)  pyramid L1..L7 -> FAST score + cell NMS -> candidate compaction
+//                  (candidates land in host-mapped memory) ; blur queued behind it
+//   selection      host worker pool, one task per (image, level)        [mcorb_select.cpp]
+//   phase B (GPU)  BRIEF descriptors for the selected keypoints -> D2H
+//   match (GPU)    all-pairs Hamming k-NN (k=2) + ratio/threshold flags -> host-mapped
+//   merge          per-frame IntraMatch track merge on the host
+// Each slot owns a stream, a complete buffer set and a driver thread, so several
+// batches can be in flight and the host stage of one overlaps the GPU phases of others.
+#include "mcorb_engine.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <chrono>
+
+namespace mcorb {
+
+static thread_local std::string g_err;
+void set_error(const std::string &msg) { g_err = msg; }
+const char *get_error() { return g_err.c_str(); }
+
+#define HIPCHK(x)                                                                      \
+    do {                                                                               \
+        hipError_t e_ = (x);                                                           \
+        if (e_ != hipSuccess) {                                                        \
+            set_error(std::string(#x) + ": " + hipGetErrorString(e_));                 \
+            return MCORB_E_HIP;                                                        \
+        }                                                                              \
+    } while (0)
+
+static inline int cv_round_f(float v) { return (int)lrintf(v); }
+static inline int cv_round_d(double v) { return (int)lrint(v); }
+static inline int cv_floor_f(float v) { int i = (int)v; return i - (i > v); }
+static inline int cv_ceil_f(float v) { int i = (int)v; return i + (i < v); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---------------------------------------------------------------------------
+// ORBextractor::ORBextractor (ORBextractor.cpp:408-468).  scaleFactor is a
+// double member initialised from a float argument (ORBextractor.h:103).
+// ---------------------------------------------------------------------------
+int compute_tables(const mcorb_params &p, Tables &t)
+{
+    if (p.nlevels < 1 || p.nlevels > kMaxLevels || p.nfeatures < 1 || !(p.scale_factor > 1.0f)) {
+        set_error("bad extractor parameters");
+        return MCORB_E_ARG;
+    }
+    const int L = p.nlevels;
+    const double sf = (double)p.scale_factor;
+    t.nlevels = L;
+    t.scale[0] = 1.0f;
+    t.sigma2[0] = 1.0f;
+    for (int i = 1; i < L; i++) {
+        t.scale[i] = (float)((double)t.scale[i - 1] * sf);
+        t.sigma2[i] = t.scale[i] * t.scale[i];
+    }
+    for (int i = 0; i < L; i++) {
+        t.inv_scale[i] = 1.0f / t.scale[i];
+        t.inv_sigma2[i] = 1.0f / t.sigma2[i];
+        t.scaled_patch[i] = (int)(31 * t.scale[i]);   // PATCH_SIZE*mvScaleFactor[level] (:879)
+    }
+    const float factor = (float)(1.0 / sf);
+    float desired = (float)p.nfeatures * (1 - factor) / (1 - (float)pow((double)factor, (double)L));
+    int sum = 0;
+    for (int l = 0; l < L - 1; l++) {
+        t.quota[l] = cv_round_f(desired);
+        sum += t.quota[l];
+        desired *= factor;
+    }
+    t.quota[L - 1] = std::max(p.nfeatures - sum, 0);
+    // umax (:450-467)
+    const int HP = 15;
+    int v, v0;
+    const int vmax = cv_floor_f(HP * sqrtf(2.f) / 2 + 1);
+    const int vmin = cv_ceil_f(HP * sqrtf(2.f) / 2);
+    const double hp2 = HP * HP;
+    for (v = 0; v < 16; v++) t.umax[v] = 0;
+    for (v = 0; v <= vmax; ++v) t.umax[v] = cv_round_d(sqrt(hp2 - v * v));
+    for (v = HP, v0 = 0; v >= vmin; --v) {
+        while (t.umax[v0] == t.umax[v0 + 1]) ++v0;
+        t.umax[v] = v0;
+        ++v0;
+    }
+    return MCORB_OK;
+}
+
+// cv::resize's table loop for one axis: x clamps (sx, fx), y keeps
+// the fraction and clips the row indices at use.
+void build_resize_axis(int ssize, int dsize, bool is_x, std::vector<ResizeTap> &out, int pad_to)
+{
+    const double scale = (double)ssize / dsize;
+    const size_t first = out.size();
+    for (int d = 0; d < dsize; d++) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int s = cv_floor_f(f);
+        f -= s;
+        if (is_x) {
+            if (s < 0) { f = 0; s = 0; }
+            if (s >= ssize - 1) { f = 0; s = ssize - 1; }
+        }
+        int c0 = cv_round_f((1.f - f) * 2048.f), c1 = cv_round_f(f * 2048.f);
+        c0 = std::min(std::max(c0, -32768), 32767);
+        c1 = std::min(std::max(c1, -32768), 32767);
+        int s0 = std::min(std::max(s, 0), ssize - 1);
+        int s1 = std::min(std::max(s + 1, 0), ssize - 1);
+        if (is_x && s + 1 >= ssize) { c0 = 2048; c1 = 0; }   // HResizeLinear tail: S[sx]*ONE
+        ResizeTap t;
+        t.s0 = (uint16_t)s0; t.s1 = (uint16_t)s1; t.c0 = (int16_t)c0; t.c1 = (int16_t)c1;
+        out.push_back(t);
+    }
+    while ((out.size() - first) % pad_to) out.push_back(ResizeTap{0, 0, 0, 0});
+}
+
+int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g, std::vector<ResizeTap> &taps)
+{
+    memset(&g, 0, sizeof(g));
+    taps.clear();
+    g.nlevels = t.nlevels;
+    size_t off = 0;
+    int cells = 0, tiles = 0, cellCap = 4;
+    for (int l = 0; l < t.nlevels; l++) {
+        LevelGeom &L = g.lv[l];
+        const float sc = t.inv_scale[l];
+        L.w = cv_round_f((float)W * sc);   // ORBextractor.cpp:1177-1178
+        L.h = cv_round_f((float)H * sc);
+        L.maxBorderX = L.w - kEdge + 3;
+        L.maxBorderY = L.h - kEdge + 3;
+        const float width = (float)(L.maxBorderX - kMinBorder);
+        const float height = (float)(L.maxBorderY - kMinBorder);
+        L.nCols = (int)(width / (float)kCellW);
+        L.nRows = (int)(height / (float)kCellW);
+        if (L.nCols < 1 || L.nRows < 1) {
+            set_error("image too small for the reference's 35-px cell grid at level " + std::to_string(l));
+            return MCORB_E_SIZE;
+        }
+        L.wCell = (int)ceilf(width / L.nCols);
+        L.hCell = (int)ceilf(height / L.nRows);
+        const int nIni = (int)roundf((float)(L.maxBorderX - kMinBorder) / (L.maxBorderY - kMinBorder));
+        if (nIni < 1) {
+            set_error("image too tall: DistributeOctTree would have no root node");
+            return MCORB_E_SIZE;
+        }
+        if (L.w > 4096 || L.h > 4096) { set_error("image larger than 4096 px"); return MCORB_E_SIZE; }
+        L.pitch = (int)align_up((size_t)L.w, 64);
+        L.off = (uint32_t)off;
+        off += align_up((size_t)L.pitch * L.h, 256);
+        L.cell0 = cells;
+        cells += L.nCols * L.nRows;
+        L.tilesX = (L.w + 63) / 64;
+        L.tilesY = (L.h + 15) / 16;
+        L.tile0 = tiles;
+        tiles += L.tilesX * L.tilesY;
+        cellCap = std::max(cellCap, ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2));
+        if (l > 0) {
+            L.xtab = (uint32_t)taps.size();
+            build_resize_axis(g.lv[l - 1].w, L.w, true, taps, 4);
+            L.ytab = (uint32_t)taps.size();
+            build_resize_axis(g.lv[l - 1].h, L.h, false, taps, 4);
+        }
+    }
+    g.cells = cells;
+    g.tiles = tiles;
+    g.cellCap = (int)align_up((size_t)cellCap, 4);
+    g.imgBytes = (uint32_t)(off + 256);
+    g.kcap = (int)align_up((size_t)p.nfeatures + 4 * t.nlevels + 48, 64);
+    if (g.kcap > 65535) { set_error("nfeatures too large (k-NN index is 16 bits)"); return MCORB_E_ARG; }
+    g.candCap = p.cand_cap > 0 ? p.cand_cap : 65536;
+    return MCORB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// worker pool
+// ---------------------------------------------------------------------------
+WorkerPool::WorkerPool(int nthreads)
+{
+    for (int i = 0; i < nthreads; i++) threads_.emplace_back([this, i] { run(i); });
+}
+WorkerPool::~WorkerPool()
+{
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        stop_ = true;
+    }
+    cv_.notify_all();
+    for (auto &t : threads_) t.join();
+}
+void WorkerPool::run(int widx)
+{
+    for (;;) {
+        Batch *b = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            cv_.wait(lk, [this] { return stop_ || !queue_.empty(); });
+            if (stop_ && queue_.empty()) return;
+            b = queue_.front();
+            if (b->next.load() >= b->n) {   // exhausted: drop it from the queue
+                queue_.erase(queue_.begin());
+                continue;
+            }
+        }
+        for (;;) {
+            const int t = b->next.fetch_add(1);
+            if (t >= b->n) break;
+            (*b->fn)(t, widx);
+            if (b->done.fetch_add(1) + 1 == b->n) {
+                std::lock_guard<std::mutex> lk(b->m);
+                b->cv.notify_all();
+            }
+        }
+    }
+}
+void WorkerPool::parallel_for(int n, const std::function<void(int, int)> &fn)
+{
+    if (n <= 0) return;
+    Batch b;
+    b.fn = &fn;
+    b.n = n;
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        queue_.push_back(&b);
+    }
+    cv_.notify_all();
+    {
+        std::unique_lock<std::mutex> lk(b.m);
+        b.cv.wait(lk, [&b] { return b.done.load() >= b.n; });
+    }
+    // make sure no worker still holds the pointer through the queue
+    std::lock_guard<std::mutex> lk(m_);
+    queue_.erase(std::remove(queue_.begin(), queue_.end(), &b), queue_.end());
+}
+
+// ---------------------------------------------------------------------------
+// Rig
+// ---------------------------------------------------------------------------
+template <typename T>
+static int dev_alloc(T **p, size_t n)
+{
+    HIPCHK(hipMalloc((void **)p, n * sizeof(T)));
+    return MCORB_OK;
+}
+template <typename T>
+static int host_alloc(T **p, size_t n)
+{
+    HIPCHK(hipHostMalloc((void **)p, n * sizeof(T), hipHostMallocMapped | hipHostMallocPortable));
+    memset(*p, 0, n * sizeof(T));
+    return MCORB_OK;
+}
+#define TRY(x)                       \
+    do {                             \
+        int r_ = (x);                \
+        if (r_ != MCORB_OK) return r_; \
+    } while (0)
+
+int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_, int nslots)
+{
+    if (ncams_ < 1 || ncams_ > MCORB_MAX_CAMS || max_frames_ < 1 || nslots < 1 || W_ < 1 || H_ < 1) {
+        set_error("bad rig arguments");
+        return MCORB_E_ARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p.device_id < 0 || p.device_id >= ndev) {
+        set_error("no usable HIP device (libmcorb has no CPU path)");
+        return MCORB_E_NODEVICE;
+    }
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, p.device_id));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error(std::string("device is ") + prop.gcnArchName + ", libmcorb is built for gfx950 only");
+        return MCORB_E_NODEVICE;
+    }
+    params = p;
+    ncams = ncams_; W = W_; H = H_; max_frames = max_frames_;
+    max_images = ncams * max_frames;
+    npp = ncams * (ncams - 1) / 2;
+    device = p.device_id;
+    HIPCHK(hipSetDevice(device));
+    TRY(compute_tables(p, tab));
+    std::vector<ResizeTap> taps;
+    TRY(build_geometry(p, tab, W, H, geom, taps));
+    if (taps.empty()) taps.push_back(ResizeTap{0, 0, 0, 0});
+    TRY(dev_alloc(&d_taps, taps.size()));
+    HIPCHK(hipMemcpy(d_taps, taps.data(), taps.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+    HIPCHK(upload_umax(tab.umax));
+
+    int nthreads = p.host_threads > 0 ? p.host_threads : (int)std::thread::hardware_concurrency();
+    if (nthreads < 1) nthreads = 1;
+    if (p.host_threads <= 0) nthreads = std::min(nthreads, std::max(1, max_images * 2));
+    nthreads = std::min(nthreads, 64);
+    pool = new WorkerPool(nthreads);
+    for (int i = 0; i < nthreads; i++) scratch.push_back(new SelectScratch);
+
+    const int npairs_max = std::max(1, npp * max_frames);
+    const int nchunks = (geom.kcap + kKnnChunk - 1) / kKnnChunk;
+    for (int si = 0; si < nslots; si++) {
+        Slot *s = new Slot;
+        slots.push_back(s);
+        s->rig = this;
+        s->index = si;
+        HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+        for (auto &e : s->ev) HIPCHK(hipEventCreate(&e));
+        const size_t M = (size_t)max_images;
+        TRY(dev_alloc(&s->d_pyr, M * geom.imgBytes));
+        TRY(dev_alloc(&s->d_blur, M * geom.imgBytes));
+        HIPCHK(hipMemset(s->d_pyr, 0, M * geom.imgBytes));
+        HIPCHK(hipMemset(s->d_blur, 0, M * geom.imgBytes));
+        TRY(dev_alloc(&s->d_cellkp, M * geom.cells * geom.cellCap));
+        TRY(dev_alloc(&s->d_cellcnt, M * geom.cells));
+        TRY(dev_alloc(&s->d_desc, M * geom.kcap * 32));
+        HIPCHK(hipMemset(s->d_desc, 0, M * geom.kcap * 32));
+        TRY(dev_alloc(&s->d_angles, M * geom.kcap));
+        TRY(dev_alloc(&s->d_part, (size_t)npairs_max * nchunks * geom.kcap));
+        TRY(host_alloc(&s->h_cand, M * geom.candCap));
+        TRY(host_alloc(&s->h_lvloff, M * (kMaxLevels + 1)));
+        TRY(host_alloc(&s->h_overflow, 16));
+        TRY(host_alloc(&s->h_sel, M * geom.kcap));
+        TRY(host_alloc(&s->h_nsel, M));
+        TRY(host_alloc(&s->h_knn, (size_t)npairs_max * geom.kcap));
+        TRY(host_alloc(&s->h_pairs, (size_t)npairs_max));
+        TRY(host_alloc(&s->h_extcounts, 4096));
+        TRY(host_alloc(&s->h_stage, M * (size_t)W * H));
+        TRY(host_alloc(&s->h_desc, M * geom.kcap * 32));
+        TRY(host_alloc(&s->h_angles, M * geom.kcap));
+        s->kps.resize(M);
+        s->mono.assign(M, 0);
+        s->sel_idx.resize(M * geom.nlevels);
+        s->m_idx1.resize(npairs_max);
+        s->m_idx2.resize(npairs_max);
+        s->tracks.resize(max_frames);
+        s->mergeable.assign(max_frames, 0);
+        s->th = std::thread([this, s] { driver(s); });
+    }
+    return MCORB_OK;
+}
+
+Rig::~Rig()
+{
+    for (Slot *s : slots) {
+        if (s->th.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(s->m);
+                s->quit = true;
+            }
+            s->cv.notify_all();
+            s->th.join();
+        }
+        (void)hipSetDevice(device);
+        if (s->st) (void)hipStreamSynchronize(s->st);
+        (void)hipFree(s->d_pyr); (void)hipFree(s->d_blur); (void)hipFree(s->d_desc); (void)hipFree(s->d_cellkp);
+        (void)hipFree(s->d_cellcnt); (void)hipFree(s->d_angles); (void)hipFree(s->d_part); (void)hipFree(s->d_f32);
+        (void)hipHostFree(s->h_cand); (void)hipHostFree(s->h_lvloff); (void)hipHostFree(s->h_overflow);
+        (void)hipHostFree(s->h_sel); (void)hipHostFree(s->h_nsel); (void)hipHostFree(s->h_knn);
+        (void)hipHostFree(s->h_pairs); (void)hipHostFree(s->h_extcounts); (void)hipHostFree(s->h_stage);
+        (void)hipHostFree(s->h_desc); (void)hipHostFree(s->h_angles);
+        for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
+        if (s->st) (void)hipStreamDestroy(s->st);
+        delete s;
+    }
+    slots.clear();
+    delete pool;
+    for (auto *sc : scratch) delete sc;
+    if (d_taps) (void)hipFree(d_taps);
+}
+
+// Frame staging: caller memory -> pinned buffer -> hipMemcpy2DAsync into the
+// level-0 planes (replaces the clone/convert chain of MultiCameraFrame::setData).
+int Rig::upload_u8(int slot, const uint8_t *const *images, int nimg, int stride)
+{
+    if (slot < 0 || slot >= (int)slots.size() || nimg < 1 || nimg > max_images || !images || stride < W) {
+        set_error("upload_u8: bad argument");
+        return MCORB_E_ARG;
+    }
+    Slot &s = *slots[slot];
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(s.st));   // staging buffer free again
+    for (int m = 0; m < nimg; m++) {
+        if (!images[m]) { set_error("upload_u8: empty image"); return MCORB_E_EMPTY; }
+        uint8_t *dst = s.h_stage + (size_t)m * W * H;
+        if (stride == W) memcpy(dst, images[m], (size_t)W * H);
+        else for (int y = 0; y < H; y++) memcpy(dst + (size_t)y * W, images[m] + (size_t)y * stride, W);
+        HIPCHK(hipMemcpy2DAsync(s.d_pyr + (size_t)m * geom.imgBytes + geom.lv[0].off, geom.lv[0].pitch, dst, W, W, H,
+                                hipMemcpyHostToDevice, s.st));
+    }
+    return MCORB_OK;
+}
+
+int Rig::upload_f32(int slot, const float *const *images, int nimg, int stride_bytes, int channels)
+{
+    if (slot < 0 || slot >= (int)slots.size() || nimg < 1 || nimg > max_images || !images ||
+        (channels != 1 && channels != 3) || stride_bytes < W * channels * 4 || (stride_bytes & 3)) {
+        set_error("upload_f32: bad argument");
+        return MCORB_E_ARG;
+    }
+    Slot &s = *slots[slot];
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamSynchronize(s.st));
+    const size_t row_f = (size_t)W * channels, img_f = row_f * H;
+    const size_t need = img_f * 4 * (size_t)max_images;
+    if (s.f32_bytes < need) {
+        if (s.d_f32) HIPCHK(hipFree(s.d_f32));
+        HIPCHK(hipMalloc((void **)&s.d_f32, need));
+        s.f32_bytes = need;
+    }
+    for (int m = 0; m < nimg; m++) {
+        if (!images[m]) { set_error("upload_f32: empty image"); return MCORB_E_EMPTY; }
+        HIPCHK(hipMemcpy2DAsync(s.d_f32 + (size_t)m * img_f, row_f * 4, images[m], stride_bytes, row_f * 4, H,
+                                hipMemcpyHostToDevice, s.st));
+    }
+    launch_stage_f32(s.st, s.d_f32, W, H, (int)row_f, channels, img_f, s.d_pyr, geom, nimg);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s.st));   // caller memory may be pageable: copies above were staged by the runtime
+    return MCORB_OK;
+}
+
+int Rig::submit(int slot, const Job &job)
+{
+    if (slot < 0 || slot >= (int)slots.size()) { set_error("bad slot"); return MCORB_E_ARG; }
+    Slot &s = *slots[slot];
+    std::unique_lock<std::mutex> lk(s.m);
+    if (s.busy) { set_error("slot busy"); return MCORB_E_STATE; }
+    s.job = job;
+    s.busy = true;
+    s.status = MCORB_OK;
+    lk.unlock();
+    s.cv.notify_all();
+    return MCORB_OK;
+}
+
+int Rig::wait(int slot)
+{
+    if (slot < 0 || slot >= (int)slots.size()) { set_error("bad slot"); return MCORB_E_ARG; }
+    Slot &s = *slots[slot];
+    std::unique_lock<std::mutex> lk(s.m);
+    s.cv.wait(lk, [&s] { return !s.busy; });
+    if (s.status != MCORB_OK) set_error(s.err);
+    return s.status;
+}
+
+void Rig::driver(Slot *sp)
+{
+    Slot &s = *sp;
+    (void)hipSetDevice(device);
+    for (;;) {
+        Job j;
+        {
+            std::unique_lock<std::mutex> lk(s.m);
+            s.cv.wait(lk, [&s] { return s.quit || s.busy; });
+            if (s.quit) return;
+            j = s.job;
+        }
+        int st = MCORB_OK;
+        switch (j.kind) {
+        case Job::EXTRACT:
+            st = run_extract_phaseA(s, j);
+            if (st == MCORB_OK) st = run_select_and_describe(s, j, false);
+            break;
+        case Job::PROCESS:
+            st = run_extract_phaseA(s, j);
+            if (st == MCORB_OK) st = run_select_and_describe(s, j, true);
+            if (st == MCORB_OK) st = finish_match(s, j);
+            break;
+        case Job::MATCH:
+            if (j.ext_desc) st = run_external_knn(s, j);
+            else {
+                st = enqueue_match(s, j);
+                if (st == MCORB_OK) {
+                    hipError_t e = hipStreamSynchronize(s.st);
+                    if (e != hipSuccess) { set_error(hipGetErrorString(e)); st = MCORB_E_HIP; }
+                }
+                if (st == MCORB_OK) st = finish_match(s, j);
+            }
+            break;
+        default: break;
+        }
+        {
+            std::lock_guard<std::mutex> lk(s.m);
+            s.status = st;
+            if (st != MCORB_OK) s.err = get_error();
+            s.busy = false;
+        }
+        s.cv.notify_all();
+    }
+}
+
+int Rig::run_extract_phaseA(Slot &s, const Job &j)
+{
+    if (j.nimg < 1 || j.nimg > max_images) { set_error("extract: bad image count"); return MCORB_E_ARG; }
+    s.h_overflow[0] = 0;
+    HIPCHK(hipEventRecord(s.ev[0], s.st));
+    launch_pyramid(s.st, s.d_pyr, geom, d_taps, j.nimg);
+    launch_fast(s.st, s.d_pyr, geom, params.ini_th_fast, params.min_th_fast, s.d_cellkp, s.d_cellcnt, s.h_cand,
+                s.h_lvloff, s.h_overflow, j.nimg);
+    HIPCHK(hipEventRecord(s.ev[1], s.st));
+    launch_blur(s.st, s.d_pyr, s.d_blur, geom, j.nimg);
+    HIPCHK(hipEventRecord(s.ev[2], s.st));
+    HIPCHK(hipGetLastError());
+    return MCORB_OK;
+}
+
+int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
+{
+    HIPCHK(hipEventSynchronize(s.ev[1]));
+    if (s.h_overflow[0]) {
+        set_error("FAST candidate buffer overflow (raise mcorb_params.cand_cap)");
+        (void)hipStreamSynchronize(s.st);
+        return MCORB_E_OVERFLOW;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    const int L = geom.nlevels, nimg = j.nimg;
+    std::atomic<int> bad{0};
+    // selection: one task per (level, image), large levels first
+    pool->parallel_for(L * nimg, [&](int task, int w) {
+        const int level = task / nimg, m = task - level * nimg;
+        const int *lo = s.h_lvloff + (size_t)m * (kMaxLevels + 1);
+        const int n = lo[level + 1] - lo[level];
+        std::vector<int> &out = s.sel_idx[(size_t)m * L + level];
+        out.resize((size_t)tab.quota[level] + 64);
+        const LevelGeom &G = geom.lv[level];
+        int r = 0;
+        if (n > 0)
+            r = select_octree(s.h_cand + (size_t)m * geom.candCap + lo[level], n, kMinBorder, G.maxBorderX, kMinBorder,
+                              G.maxBorderY, tab.quota[level], out.data(), *scratch[w]);
+        if (r < 0) { bad.store(1); r = 0; }
+        out.resize(r);
+    });
+    if (bad.load()) { set_error("selection failed: level too tall"); (void)hipStreamSynchronize(s.st); return MCORB_E_SIZE; }
+    // assembly (ORBextractor.cpp:1103-1170): final order, lapping partition, coordinate scaling
+    pool->parallel_for(nimg, [&](int m, int) {
+        int total = 0;
+        for (int l = 0; l < L; l++) total += (int)s.sel_idx[(size_t)m * L + l].size();
+        if (total > geom.kcap) { bad.store(2); total = 0; }
+        std::vector<mcorb_keypoint> &K = s.kps[m];
+        K.assign(total, mcorb_keypoint{});
+        uint32_t *sel = s.h_sel + (size_t)m * geom.kcap;
+        int monoIndex = 0, stereoIndex = total - 1;
+        if (total) {
+            const int *lo = s.h_lvloff + (size_t)m * (kMaxLevels + 1);
+            for (int l = 0; l < L; l++) {
+                const uint32_t *cand = s.h_cand + (size_t)m * geom.candCap + lo[l];
+                const float scale = tab.scale[l];
+                for (int idx : s.sel_idx[(size_t)m * L + l]) {
+                    const uint32_t c = cand[idx];
+                    const int xl = cand_x(c) + kMinBorder, yl = cand_y(c) + kMinBorder;
+                    mcorb_keypoint kp;
+                    kp.x = (float)xl; kp.y = (float)yl;
+                    kp.size = (float)tab.scaled_patch[l];
+                    kp.angle = 0.f;
+                    kp.response = (float)cand_resp(c);
+                    kp.octave = l;
+                    kp.class_id = -1;
+                    if (l != 0) { kp.x *= scale; kp.y *= scale; }
+                    int pos;
+                    if (kp.x >= (float)j.lap0 && kp.x <= (float)j.lap1) pos = stereoIndex--;
+                    else pos = monoIndex++;
+                    K[pos] = kp;
+                    sel[pos] = pack_sel(l, xl, yl);
+                }
+            }
+        }
+        s.mono[m] = monoIndex;
+        s.h_nsel[m] = total;
+    });
+    if (bad.load()) { set_error("keypoint capacity exceeded"); (void)hipStreamSynchronize(s.st); return MCORB_E_CAP; }
+    const auto t1 = std::chrono::steady_clock::now();
+    s.timing[1] = std::chrono::duration<float, std::micro>(t1 - t0).count();
+
+    HIPCHK(hipEventRecord(s.ev[3], s.st));
+    launch_describe(s.st, s.d_pyr, s.d_blur, geom, s.h_sel, s.h_nsel, params.orientation, s.d_desc, s.d_angles, nimg);
+    HIPCHK(hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)nimg * geom.kcap * 32, hipMemcpyDeviceToHost, s.st));
+    if (params.orientation)
+        HIPCHK(hipMemcpyAsync(s.h_angles, s.d_angles, (size_t)nimg * geom.kcap * sizeof(float), hipMemcpyDeviceToHost, s.st));
+    HIPCHK(hipEventRecord(s.ev[4], s.st));
+    s.nimg_done = nimg;
+    if (then_match) TRY(enqueue_match(s, j));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s.st));
+    if (params.orientation)
+        for (int m = 0; m < nimg; m++)
+            for (size_t k = 0; k < s.kps[m].size(); k++) s.kps[m][k].angle = s.h_angles[(size_t)m * geom.kcap + k];
+    s.nimg_done = nimg;
+    float a = 0, b = 0, c = 0;
+    (void)hipEventElapsedTime(&a, s.ev[0], s.ev[1]);
+    (void)hipEventElapsedTime(&b, s.ev[1], s.ev[2]);
+    (void)hipEventElapsedTime(&c, s.ev[3], s.ev[4]);
+    s.timing[0] = a * 1000.f;
+    s.timing[2] = (b + c) * 1000.f;
+    return MCORB_OK;
+}
+
+int Rig::enqueue_match(Slot &s, const Job &j)
+{
+    if (j.nframes < 1 || j.nframes > max_frames || j.nframes * ncams > s.nimg_done) {
+        set_error("match: bad frame count or features not extracted");
+        return MCORB_E_STATE;
+    }
+    if (npp == 0) { s.npairs_done = 0; s.nframes_done = j.nframes; return MCORB_OK; }
+    int p = 0;
+    for (int f = 0; f < j.nframes; f++)
+        for (int a = 0; a < ncams - 1; a++)
+            for (int b = a + 1; b < ncams; b++) s.h_pairs[p++] = int2{f * ncams + a, f * ncams + b};
+    HIPCHK(hipEventRecord(s.ev[5], s.st));
+    launch_knn2(s.st, s.d_desc, s.h_nsel, s.h_pairs, p, geom.kcap, s.d_part, j.dist_thresh, j.ratio, s.h_knn);
+    HIPCHK(hipEventRecord(s.ev[6], s.st));
+    HIPCHK(hipGetLastError());
+    s.npairs_done = p;
+    s.nframes_done = j.nframes;
+    return MCORB_OK;
+}
+
+// BruteForceMatch's output lists + computeIntraMatches' track merge
+// (MultiCameraFrame.cpp:1060-1078, 1167-1268), host side, after the k-NN tables landed.
+int Rig::finish_match(Slot &s, const Job &j)
+{
+    const int C = ncams;
+    for (int f = 0; f < s.nframes_done; f++) {
+        std::vector<int32_t> &tr = s.tracks[f];
+        tr.clear();
+        int ntr = 0, mergeable = 0;
+        std::vector<std::vector<int>> inv(C);
+        for (int c = 0; c < C; c++) inv[c].assign(s.kps[f * C + c].size(), -1);
+        int pi = f * npp;
+        for (int a = 0; a < C - 1; a++) {
+            for (int b = a + 1; b < C; b++, pi++) {
+                std::vector<uint32_t> &i1 = s.m_idx1[pi], &i2 = s.m_idx2[pi];
+                i1.clear(); i2.clear();
+                const int nq = s.h_nsel[f * C + a];
+                const KnnRow *rows = s.h_knn + (size_t)pi * geom.kcap;
+                for (int q = 0; q < nq; q++) {
+                    const KnnRow &r = rows[q];
+                    if (r.idx1 >= 0 && ((r.d1 >> 30) & 1)) { i1.push_back((uint32_t)q); i2.push_back((uint32_t)r.idx0); }
+                }
+                for (size_t k = 0; k < i1.size(); k++) {
+                    const int fa = (int)i1[k], fb = (int)i2[k];
+                    const int ma = inv[a][fa], mb = inv[b][fb];
+                    if (ma == -1 && mb == -1) {
+                        tr.resize((size_t)(ntr + 1) * C, -1);
+                        tr[(size_t)ntr * C + a] = fa;
+                        tr[(size_t)ntr * C + b] = fb;
+                        inv[a][fa] = ntr;
+                        inv[b][fb] = ntr;
+                        ntr++;
+                    } else {
+                        if (ma == -1 && mb != -1) {
+                            if (tr[(size_t)mb * C + a] == -1) {
+                                tr[(size_t)mb * C + a] = fa;
+                                inv[a][fa] = mb;
+                            }
+                        }
+                        if (ma != -1 && mb != -1) {
+                            if (ma != mb) mergeable++;
+                        }
+                        if (ma != -1 && mb == -1) {
+                            tr[(size_t)ma * C + b] = fb;
+                            inv[b][fb] = ma;
+                        }
+                    }
+                }
+            }
+        }
+        s.mergeable[f] = mergeable;
+    }
+    if (s.npairs_done > 0) {
+        float m = 0;
+        (void)hipEventElapsedTime(&m, s.ev[5], s.ev[6]);
+        s.timing[3] = m * 1000.f;
+    }
+    (void)j;
+    return MCORB_OK;
+}
+
+int Rig::run_external_knn(Slot &s, const Job &j)
+{
+    if (j.ext_total < 1 || j.ext_total > 4096 || j.ext_npairs < 1) { set_error("external knn: bad sizes"); return MCORB_E_ARG; }
+    const int nchunks = (geom.kcap + kKnnChunk - 1) / kKnnChunk;
+    const int npairs_max = std::max(1, npp * max_frames);
+    if (j.ext_npairs > npairs_max) { set_error("external knn: too many pairs for this rig's buffers"); return MCORB_E_CAP; }
+    (void)nchunks;
+    for (int i = 0; i < j.ext_total; i++) s.h_extcounts[i] = j.ext_counts[i];
+    for (int i = 0; i < j.ext_npairs; i++) s.h_pairs[i] = int2{j.ext_pairs[2 * i], j.ext_pairs[2 * i + 1]};
+    launch_knn2(s.st, (const uint8_t *)j.ext_desc, s.h_extcounts, s.h_pairs, j.ext_npairs, geom.kcap, s.d_part,
+                j.dist_thresh, j.ratio, s.h_knn);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s.st));
+    s.npairs_done = j.ext_npairs;
+    return MCORB_OK;
+}
+
+}  // namespace mcorb

@@ -1,0 +1,152 @@
+// mcorb_engine.h -- host orchestration of the gfx950 ORB front-end.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mcorb.h"
+#include "mcorb_common.h"
+#include "mcorb_kernels.h"
+#include "mcorb_select.h"
+
+namespace mcorb {
+
+void set_error(const std::string &msg);
+const char *get_error();
+
+// ORBextractor constructor tables (ORBextractor.cpp:408-468)
+struct Tables {
+    int nlevels = 0;
+    float scale[kMaxLevels], inv_scale[kMaxLevels], sigma2[kMaxLevels], inv_sigma2[kMaxLevels];
+    int quota[kMaxLevels];
+    int scaled_patch[kMaxLevels];
+    int umax[16];
+};
+int compute_tables(const mcorb_params &p, Tables &t);
+
+// cv::resize's per-axis tables, folded into ResizeTap entries
+void build_resize_axis(int ssize, int dsize, bool is_x, std::vector<ResizeTap> &out, int pad_to);
+
+// level / cell / tile geometry for W x H; returns MCORB_OK or MCORB_E_SIZE
+int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g, std::vector<ResizeTap> &taps);
+
+class WorkerPool {
+public:
+    explicit WorkerPool(int nthreads);
+    ~WorkerPool();
+    // runs fn(task, worker_index) for task in [0, n); returns when all are done
+    void parallel_for(int n, const std::function<void(int, int)> &fn);
+    int size() const { return (int)threads_.size(); }
+
+private:
+    struct Batch {
+        const std::function<void(int, int)> *fn;
+        std::atomic<int> next{0};
+        int n = 0;
+        std::atomic<int> done{0};
+        std::mutex m;
+        std::condition_variable cv;
+    };
+    void run(int widx);
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<Batch *> queue_;
+    bool stop_ = false;
+};
+
+struct Job {
+    enum Kind { NONE, EXTRACT, MATCH, PROCESS } kind = NONE;
+    int nimg = 0, nframes = 0, lap0 = 0, lap1 = 0;
+    float dist_thresh = 75.f, ratio = 0.85f;
+    // external k-NN (RCCL path)
+    const void *ext_desc = nullptr;
+    const int32_t *ext_counts = nullptr;
+    int ext_total = 0;
+    const int32_t *ext_pairs = nullptr;
+    int ext_npairs = 0;
+};
+
+class Rig;
+
+struct Slot {
+    Rig *rig = nullptr;
+    int index = 0;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[8] = {};   // 0 A-start, 1 FAST done, 2 blur done, 3/4 describe, 5/6 match
+    // device
+    uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_desc = nullptr;
+    uint32_t *d_cellkp = nullptr;
+    int *d_cellcnt = nullptr;
+    float *d_angles = nullptr, *d_f32 = nullptr;
+    uint2 *d_part = nullptr;
+    size_t f32_bytes = 0;
+    // host, device-mapped (kernels write/read these directly over PCIe)
+    uint32_t *h_cand = nullptr;
+    int *h_lvloff = nullptr, *h_overflow = nullptr;
+    uint32_t *h_sel = nullptr;
+    int *h_nsel = nullptr;
+    KnnRow *h_knn = nullptr;
+    int2 *h_pairs = nullptr;
+    int *h_extcounts = nullptr;
+    // host, pinned
+    uint8_t *h_stage = nullptr, *h_desc = nullptr;
+    float *h_angles = nullptr;
+    // results
+    std::vector<std::vector<mcorb_keypoint>> kps;   // per image
+    std::vector<int> mono;
+    std::vector<std::vector<int>> sel_idx;          // per (image, level): retained candidate indices
+    int npairs_done = 0, nframes_done = 0, nimg_done = 0;
+    std::vector<std::vector<uint32_t>> m_idx1, m_idx2;   // per pair
+    std::vector<std::vector<int32_t>> tracks;            // per frame, ncams ints per track
+    std::vector<int> mergeable;
+    float timing[4] = {0, 0, 0, 0};
+    // driver thread
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    Job job;
+    bool busy = false, quit = false;
+    int status = MCORB_OK;
+    std::string err;
+    bool upload_pending = false;
+};
+
+class Rig {
+public:
+    Rig() = default;
+    ~Rig();
+    int init(const mcorb_params &p, int ncams, int W, int H, int max_frames, int nslots);
+
+    int upload_u8(int slot, const uint8_t *const *images, int nimg, int stride);
+    int upload_f32(int slot, const float *const *images, int nimg, int stride_bytes, int channels);
+    int submit(int slot, const Job &job);
+    int wait(int slot);
+
+    mcorb_params params;
+    Tables tab;
+    Geom geom;
+    int ncams = 0, W = 0, H = 0, max_frames = 0, max_images = 0, npp = 0 /* pairs per frame */;
+    int device = 0;
+    ResizeTap *d_taps = nullptr;
+    std::vector<Slot *> slots;
+    WorkerPool *pool = nullptr;
+    std::vector<SelectScratch *> scratch;   // one per worker
+
+private:
+    void driver(Slot *s);
+    int run_extract_phaseA(Slot &s, const Job &j);
+    int run_select_and_describe(Slot &s, const Job &j, bool then_match);
+    int enqueue_match(Slot &s, const Job &j);
+    int finish_match(Slot &s, const Job &j);
+    int run_external_knn(Slot &s, const Job &j);
+};
+
+}  // namespace mcorb
