@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""bench.py -- multi-camera ORB front-end throughput on MI355X.
+
+Workload (BASELINE.json configs[1]): 4-camera rig, 1280x720, 2000 keypoints/camera,
+extract + all-pairs intra-rig match.  One *step* = one batch of F synthetic rig
+frames per rank through the whole hot path (pyramid -> FAST -> selection -> blur ->
+BRIEF -> k-NN(k=2) + ratio filter -> track merge), inputs resident in HBM before the
+timed region.  `value` = rig frames / second over all ranks.
+
+N = 1: cameras and pairs all on one GPU, S slots in flight (the host selection stage
+of one sub-batch overlaps the GPU phases of the others).
+N > 1 (weak scaling, F frames per rank per step, F*N frames per step in total):
+camera c of frame f is extracted on rank (c + f) mod N; per-camera descriptors are
+exchanged with ONE RCCL all-gather per step; frame f is matched on rank f mod N.
+
+Extra legs on rank 0 at N = 1: `cpu_baseline` (the CPU oracle, one thread per camera
+as the reference's extractFeaturesParallel does, on a bounded sample) and a bit-exact
+GPU-vs-oracle check of the first frame.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "tests")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+
+W, H, NCAMS, NFEAT = 1280, 720, 4, 2000
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+
+
+def level_pixels(rig):
+    return [rig.level_size(l) for l in range(rig.nlevels)]
+
+
+def algorithmic_bytes(kernel, S, S0, s_last, K, Kc, npairs_per_frame=6):
+    """Per camera image (or per frame for knn2), SURVEY.md 8(d) with this build's record sizes."""
+    if kernel == "k_fast_cells":      # read every level once + packed 4-byte candidate records out
+        return S + 4 * Kc
+    if kernel == "k_resize":          # read levels 0..n-2, write levels 1..n-1
+        return (S - s_last) + (S - S0)
+    if kernel == "k_blur":
+        return 2 * S
+    if kernel == "k_describe":
+        return K * (512 + 32)
+    if kernel == "k_knn2":            # per pair: both descriptor sets once + 8-byte partial per query
+        return 2 * K * 32 + K * 16
+    raise KeyError(kernel)
+
+
+def cpu_baseline(frames, ncams):
+    """Oracle timed the way the reference runs: one thread per camera for extraction
+    (MultiCameraFrame.cpp:212-227), matching + track merge on the calling thread."""
+    import mcorb
+    import oracle_lib as O
+    exs = [O.OracleExtractor(NFEAT) for _ in range(ncams)]
+    times, first = [], None
+    for f in frames:
+        imgs = [mcorb.synth_rig_frame(f, ncams, c, W, H) for c in range(ncams)]
+        res = [None] * ncams
+        t0 = time.perf_counter()
+
+        def work(c):
+            res[c] = exs[c](imgs[c])
+        ths = [threading.Thread(target=work, args=(c,)) for c in range(ncams)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        tracks, _ = O.intra_matches([r[2] for r in res])
+        times.append(time.perf_counter() - t0)
+        if first is None:
+            first = (imgs, res, tracks)
+    return times, first
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=8, help="rig frames per rank per step")
+    ap.add_argument("--slots", type=int, default=2, help="sub-batches in flight per rank")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-frames", type=int, default=24)
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); 'gloo' only to rehearse N>1 on a 1-GPU box")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses device 0")
+    args = ap.parse_args()
+
+    import torch
+    import mcorb
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    N = args.gpus
+    if world != N and not (N == 1 and world == 1):
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (N, world))
+    if args.single_device:
+        local = 0
+    torch.cuda.set_device(local)
+    dist = None
+    gloo = args.dist_backend == "gloo"
+    if N > 1:
+        import torch.distributed as dist
+        if gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    F, S = args.frames, max(1, min(args.slots, args.frames))
+    fps = F // S                       # rig frames per slot
+    if fps * S != F:
+        raise SystemExit("--frames must be a multiple of --slots")
+    rig = mcorb.Rig(NCAMS, W, H, max_frames=fps, nslots=S, nfeatures=NFEAT, device_id=local)
+    kcap = rig.kcap
+    total_frames = F * N
+
+    # ---- inputs: synthetic rig frames, staged into HBM before the timed region ----
+    from importlib import import_module
+    shard = import_module("mc-slam_amd.sharding")
+    if N == 1:
+        mine = [(f, c) for f in range(F) for c in range(NCAMS)]
+    else:
+        mine = shard.images_of_rank(rank, N, NCAMS, total_frames)
+    assert len(mine) == F * NCAMS, (len(mine), F * NCAMS)
+    per_slot = fps * NCAMS
+    for s in range(S):
+        imgs = [mcorb.synth_rig_frame(f, NCAMS, c, W, H) for (f, c) in mine[s * per_slot:(s + 1) * per_slot]]
+        rig.upload(imgs, slot=s)
+
+    if N > 1:
+        local_desc = torch.zeros((F * NCAMS, kcap, 32), dtype=torch.uint8, device="cuda")
+        all_desc = torch.zeros((N * F * NCAMS, kcap, 32), dtype=torch.uint8, device="cuda")
+        local_cnt = torch.zeros(F * NCAMS, dtype=torch.int32, device="cuda")
+        all_cnt = torch.zeros(N * F * NCAMS, dtype=torch.int32, device="cuda")
+        my_frames, sets = shard.match_sets(rank, N, NCAMS, total_frames)   # gathered set index of (f, c)
+        assert len(my_frames) == F
+
+    def step():
+        if N == 1:
+            for s in range(S):
+                rig.process_submit(fps, slot=s)
+            for s in range(S):
+                rig.process_wait(slot=s)
+        else:
+            for s in range(S):
+                rig.extract_submit(per_slot, slot=s)
+            for s in range(S):
+                rig.extract_wait(slot=s)
+                cnt = rig.export_descriptors(local_desc[s * per_slot].data_ptr(), per_slot, slot=s)
+                local_cnt[s * per_slot:(s + 1) * per_slot] = torch.from_numpy(cnt).cuda()
+            if gloo:                                            # rehearsal path only
+                hd, hc = torch.zeros(all_desc.shape, dtype=torch.uint8), torch.zeros(all_cnt.shape, dtype=torch.int32)
+                dist.all_gather_into_tensor(hd, local_desc.cpu())
+                dist.all_gather_into_tensor(hc, local_cnt.cpu())
+                all_desc.copy_(hd)
+                all_cnt.copy_(hc)
+            else:
+                dist.all_gather_into_tensor(all_desc, local_desc)   # the exchange step (RCCL over xGMI)
+                dist.all_gather_into_tensor(all_cnt, local_cnt)
+            counts = all_cnt.cpu().numpy()                      # syncs the collective
+            for s in range(S):                                  # this rank's frames, split over the slots
+                part = sets[s * fps:(s + 1) * fps]
+                rig.match_external(all_desc.data_ptr(), counts, part, slot=s)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # per-kernel durations, accumulated from the HIP events the engine records on each slot's stream
+    ksum = {"k_resize": 0.0, "k_fast_cells": 0.0, "k_compact": 0.0, "blur+describe": 0.0, "k_knn2": 0.0,
+            "select_host": 0.0}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for s in range(S):
+            t = rig.timing(slot=s)
+            ksum["k_resize"] += t["pyramid_us"]
+            ksum["k_fast_cells"] += t["fast_us"]
+            ksum["k_compact"] += t["compact_us"]
+            ksum["blur+describe"] += t["phase_b_us"]
+            ksum["k_knn2"] += t["knn2_us"]
+            ksum["select_host"] += t["select_us"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    value = total_frames * args.steps / dt
+    launches = args.steps * S
+    # workload constants for the algorithmic-byte formulas
+    lv = level_pixels(rig)
+    Spx = sum(w * h for w, h in lv)
+    S0, s_last = lv[0][0] * lv[0][1], lv[-1][0] * lv[-1][1]
+    nimg_launch = per_slot
+    Kc = np.mean([sum(len(rig.candidates(m, l, slot=0)[0]) for l in range(rig.nlevels)) for m in range(min(4, per_slot))])
+    K = np.mean([rig.features(m, slot=0)[1].shape[0] for m in range(min(4, per_slot))]) if N == 1 else NFEAT
+    gpu_kernels = {k: v for k, v in ksum.items() if k.startswith("k_")}
+    dominant = max(gpu_kernels, key=gpu_kernels.get)
+    avg_us = gpu_kernels[dominant] / launches
+    if dominant == "k_knn2":
+        unit_bytes, units = algorithmic_bytes(dominant, Spx, S0, s_last, K, Kc), 6 * fps
+    else:
+        unit_bytes, units = algorithmic_bytes(dominant, Spx, S0, s_last, K, Kc), nimg_launch
+    achieved = unit_bytes * units / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if measured
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(dominant, {}).get("bytes_per_launch")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "multi-cam frames/sec (4-cam 1280x720 @2000 kpts/cam, extract + intra-rig match)",
+        "value": round(value, 2), "unit": "frames/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_frame": round(dt / args.steps / total_frames * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "4-cam rig 1280x720, 2000 kpts/cam, extract + all-pairs intra-rig match (configs[1])",
+                   "frames_per_rank_per_step": F, "slots": S, "cameras": NCAMS, "nfeatures": NFEAT,
+                   "sharding": "single GPU" if N == 1 else "camera (c+f) mod N for extraction, RCCL all-gather of descriptors, frame f mod N for matching"},
+        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(unit_bytes * units),
+                     "images_per_launch": nimg_launch, "fast_candidates_per_image": int(Kc)},
+        "kernel_us_per_step": {k: round(v / args.steps, 2) for k, v in ksum.items()},
+    }
+
+    if N == 1 and not args.no_cpu:
+        ncpu = os.cpu_count()
+        times, first = cpu_baseline(list(range(2 + args.cpu_frames)), NCAMS)
+        times = np.array(times[2:])
+        out["cpu_baseline"] = {"value": round(1.0 / float(np.median(times)), 3), "unit": "frames/s", "cores": NCAMS,
+                               "kind": "port",
+                               "sample": "%d rig frames (4-cam 1280x720 @2000) after 2 warm-ups, CPU oracle, one thread per "
+                                         "camera for extraction + matching on the caller thread; median %.1f ms, p95 %.1f ms; "
+                                         "host has %d logical cores" % (len(times), np.median(times) * 1e3,
+                                                                        np.percentile(times, 95) * 1e3, ncpu)}
+        # bit-exact check of frame 0 against the oracle (slot 0 holds frames 0..fps-1)
+        imgs, res, tracks = first
+        ok = True
+        for c in range(NCAMS):
+            mono, k, d = res[c]
+            m2, k2, d2 = rig.features(c, slot=0)
+            ok &= mono == m2 and len(k) == len(k2) and all(np.array_equal(k[f], k2[f]) for f in k.dtype.names) \
+                and np.array_equal(d, d2)
+        tr, _ = rig.tracks(0, slot=0)
+        ok &= np.array_equal(tr, tracks)
+        out["gpu_equals_oracle_frame0"] = bool(ok)
+    print(json.dumps(out), flush=True)
+    rig.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

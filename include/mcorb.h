@@ -57,7 +57,7 @@ typedef struct mcorb_params {
     int orientation;      /* MCORB_ORIENT_* */
     int device_id;        /* HIP device ordinal */
     int host_threads;     /* selection workers; 0 = one per camera image, capped at hw concurrency */
-    int cand_cap;         /* FAST candidates kept per image; 0 = default (65536) */
+    int cand_cap;         /* FAST candidates kept per image; 0 = default (max(65536, w*h/4)) */
     int reserved[7];
 } mcorb_params;
 
@@ -141,24 +141,28 @@ int mcorb_rig_get_blurred(mcorb_rig *r, int slot, int m, int level, uint8_t *dst
 /* vToDistributeKeys of a level (ORBextractor.cpp:793-871): packed (y<<20 | x<<8 | response) */
 int mcorb_rig_get_candidates(mcorb_rig *r, int slot, int m, int level, uint32_t *packed, int cap, int *n_out);
 
-/* timing of the last completed extract/match of a slot, microseconds of GPU
- * time between HIP events on the slot's stream: [0] pyramid+FAST phase,
- * [1] host selection wall time, [2] blur+descriptor phase, [3] match phase */
-int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[4]);
+/* timing of the last completed job of a slot, microseconds between HIP events
+ * recorded on the slot's stream around the launches:
+ * [0] pyramid+FAST+compaction, [1] host selection wall time, [2] blur + describe(+D2H),
+ * [3] k-NN + finalize, [4] pyramid launches, [5] FAST kernel alone, [6] compaction kernel,
+ * [7] k-NN kernel alone */
+int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[8]);
 
-/* multi-GPU plumbing: raw device pointers/stream of a slot so that a caller's
- * collective (RCCL all-gather) can move per-camera descriptors between ranks.
- * Descriptor block layout: [max_images][kcap][32] bytes, counts int32[max_images]. */
+/* multi-GPU plumbing (one process per GPU; the collective itself is the
+ * caller's, e.g. an RCCL all-gather over torch.distributed).
+ * Descriptor block layout on the device: [sets][kcap][32] bytes. */
 int mcorb_rig_kcap(mcorb_rig *r);
 void *mcorb_rig_desc_device_ptr(mcorb_rig *r, int slot);
 void *mcorb_rig_stream(mcorb_rig *r, int slot);
-/* All-pairs k-NN (k=2) on caller-provided device memory: `desc_dev` holds
- * ntotal descriptor sets [ntotal][kcap][32]; counts are host ints; pairs are
- * (query set, train set) indices.  Results as mcorb_rig_get_pair_knn2, host
- * arrays of npairs x kcap x 2.  Used by the RCCL path after the all-gather. */
-int mcorb_rig_knn2_external(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts,
-                            int ntotal, const int32_t *pairs_qt, int npairs,
-                            int32_t *idx, int32_t *dist);
+/* copy the first nimg descriptor sets of a slot into caller device memory
+ * (e.g. a tensor that is then all-gathered); counts_host receives the counts */
+int mcorb_rig_export_descriptors(mcorb_rig *r, int slot, void *dst_dev, int32_t *counts_host, int nimg);
+/* computeIntraMatches(matches,false) over an external (all-gathered) descriptor
+ * block: `ntotal` sets with counts[set] descriptors each; sets[f*ncams + c] names
+ * the set that holds camera c of frame f.  Results are read back with
+ * mcorb_rig_get_pair_matches / _get_pair_knn2 / _get_tracks as for mcorb_rig_match. */
+int mcorb_rig_match_external(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts, int ntotal,
+                             const int32_t *sets, int nframes, float dist_thresh, float ratio);
 
 /* ------------------------------------------------------------------------- */
 /* Single-camera extractor: ORBextractor (ORBextractor.h:43-116)              */
@@ -199,6 +203,23 @@ int mcorb_knn2(mcorb_t *e, const uint8_t *q, int nq, const uint8_t *t, int nt, i
 /* BruteForceMatch (MultiCameraFrame.cpp:1024-1086): knn2 + ratio/threshold filter */
 int mcorb_match_ratio(mcorb_t *e, const uint8_t *q, int nq, const uint8_t *t, int nt,
                       float dist_thresh, float ratio, uint32_t *idx1, uint32_t *idx2, int cap, int *n_out);
+
+/* ------------------------------------------------------------------------- */
+/* Host stages exposed for the CPU test-suite (no device needed)              */
+/* ------------------------------------------------------------------------- */
+/* The engine's quad-tree selection stage, DistributeOctTree's equivalent
+ * (ORBextractor.cpp:554-778): packed candidates (y<<20 | x<<8 | response, x/y
+ * relative to minBorder) in vToDistributeKeys order -> indices of the retained
+ * candidates in result order.  Returns the count, MCORB_E_SIZE, or MCORB_E_CAP. */
+int mcorb_host_select(const uint32_t *packed, int n, int minX, int maxX, int minY, int maxY,
+                      int nfeatures_level, int32_t *out_idx, int cap);
+/* The engine's cv::resize coefficient table for one axis: per destination index
+ * (s0, s1, c0, c1) as int32 quadruples (x axis: clamped per HResizeLinear; y axis:
+ * row indices clipped, fraction kept). */
+int mcorb_host_resize_axis(int ssize, int dsize, int is_x, int32_t *quads);
+/* level geometry the engine derives for a w x h image: per level
+ * {w, h, nCols, nRows, wCell, hCell}; returns MCORB_OK or MCORB_E_SIZE */
+int mcorb_host_geometry(const mcorb_params *p, int w, int h, int32_t *six_per_level);
 
 /* ------------------------------------------------------------------------- */
 /* Synthetic input; host utility, see csrc/mcorb_synth.c       */

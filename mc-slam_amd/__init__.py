@@ -166,18 +166,22 @@ class Rig:
         return ((p >> 8) & 0xfff).astype(np.int32), (p >> 20).astype(np.int32), (p & 0xff).astype(np.int32)
 
     def timing(self, slot=0):
-        t = (C.c_float * 4)()
+        t = (C.c_float * 8)()
         _lib.check(self.L.mcorb_rig_last_timing(self.h_rig, slot, t))
-        return dict(phase_a_us=t[0], select_us=t[1], phase_b_us=t[2], match_us=t[3])
+        return dict(phase_a_us=t[0], select_us=t[1], phase_b_us=t[2], match_us=t[3], pyramid_us=t[4],
+                    fast_us=t[5], compact_us=t[6], knn2_us=t[7])
 
-    def knn2_external(self, desc_dev_ptr, counts, pairs, slot=0):
+    # -- multi-GPU plumbing ---------------------------------------------------
+    def export_descriptors(self, dst_dev_ptr, nimg, slot=0):
+        counts = np.zeros(nimg, np.int32)
+        _lib.check(self.L.mcorb_rig_export_descriptors(self.h_rig, slot, dst_dev_ptr, counts.ctypes.data, nimg))
+        return counts
+
+    def match_external(self, desc_dev_ptr, counts, sets, slot=0, dist_thresh=75.0, ratio=0.85):
         counts = np.ascontiguousarray(counts, np.int32)
-        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
-        idx = np.zeros((len(pairs), self.kcap, 2), np.int32)
-        dist = np.zeros((len(pairs), self.kcap, 2), np.int32)
-        _lib.check(self.L.mcorb_rig_knn2_external(self.h_rig, slot, desc_dev_ptr, counts.ctypes.data, len(counts),
-                                                  pairs.ctypes.data, len(pairs), idx.ctypes.data, dist.ctypes.data))
-        return idx, dist
+        sets = np.ascontiguousarray(sets, np.int32).reshape(-1, self.ncams)
+        _lib.check(self.L.mcorb_rig_match_external(self.h_rig, slot, desc_dev_ptr, counts.ctypes.data, len(counts),
+                                                   sets.ctypes.data, len(sets), dist_thresh, ratio))
 
 
 class ORBextractor:

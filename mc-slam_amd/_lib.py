@@ -67,7 +67,8 @@ SIGNATURES = {
     "mcorb_rig_kcap": (_i, [_vp]),
     "mcorb_rig_desc_device_ptr": (_vp, [_vp, _i]),
     "mcorb_rig_stream": (_vp, [_vp, _i]),
-    "mcorb_rig_knn2_external": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp, _vp]),
+    "mcorb_rig_export_descriptors": (_i, [_vp, _i, _vp, _vp, _i]),
+    "mcorb_rig_match_external": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _f, _f]),
     "mcorb_create": (_i, [C.POINTER(Params), _i, _i, C.POINTER(_vp)]),
     "mcorb_destroy": (None, [_vp]),
     "mcorb_extract": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _ip, _ip]),
@@ -77,6 +78,9 @@ SIGNATURES = {
     "mcorb_hamming256": (_i, [_vp, _vp]),
     "mcorb_knn2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "mcorb_match_ratio": (_i, [_vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _i, _ip]),
+    "mcorb_host_select": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i]),
+    "mcorb_host_resize_axis": (_i, [_i, _i, _i, _vp]),
+    "mcorb_host_geometry": (_i, [C.POINTER(Params), _i, _i, _vp]),
     "mcorb_synth_rig_frame": (_i, [C.c_uint32, _i, _i, _i, _i, _vp, _i]),
 }
 

@@ -211,7 +211,7 @@ int mcorb_rig_get_pair_knn2(mcorb_rig *r, int slot, int frame, int cam_i, int ca
     if (!s) return MCORB_E_STATE;
     const int pi = pair_index(r->rig, frame, cam_i, cam_j);
     if (frame < 0 || frame >= s->nframes_done || pi < 0) { set_error("bad frame/pair"); return MCORB_E_ARG; }
-    const int nq = s->h_nsel[frame * r->rig.ncams + cam_i];
+    const int nq = s->match_counts[frame * r->rig.ncams + cam_i];
     if (nq_out) *nq_out = nq;
     if (nq > cap_rows) { set_error("knn buffer too small"); return MCORB_E_CAP; }
     decode_rows(s->h_knn + (size_t)pi * r->rig.geom.kcap, nq, idx, dist);
@@ -279,11 +279,11 @@ int mcorb_rig_get_candidates(mcorb_rig *r, int slot, int m, int level, uint32_t 
     return MCORB_OK;
 }
 
-int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[4])
+int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[8])
 {
     Slot *s = get_slot(r, slot);
     if (!s) return MCORB_E_STATE;
-    for (int i = 0; i < 4; i++) us[i] = s->timing[i];
+    for (int i = 0; i < 8; i++) us[i] = s->timing[i];
     return MCORB_OK;
 }
 
@@ -299,25 +299,26 @@ void *mcorb_rig_stream(mcorb_rig *r, int slot)
     return (void *)r->rig.slots[slot]->st;
 }
 
-int mcorb_rig_knn2_external(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts, int ntotal,
-                            const int32_t *pairs_qt, int npairs, int32_t *idx, int32_t *dist)
+int mcorb_rig_match_external(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts, int ntotal,
+                             const int32_t *sets, int nframes, float dist_thresh, float ratio)
 {
-    if (!r || !desc_dev || !counts || !pairs_qt || !idx || !dist) { set_error("null argument"); return MCORB_E_ARG; }
+    if (!r || !desc_dev || !counts || !sets) { set_error("null argument"); return MCORB_E_ARG; }
     Job j;
-    j.kind = Job::MATCH;
-    j.ext_desc = desc_dev; j.ext_counts = counts; j.ext_total = ntotal; j.ext_pairs = pairs_qt; j.ext_npairs = npairs;
-    int st = r->rig.submit(slot, j);
-    if (st != MCORB_OK) return st;
-    st = r->rig.wait(slot);
-    if (st != MCORB_OK) return st;
-    Slot *s = r->rig.slots[slot];
-    const int kcap = r->rig.geom.kcap;
-    for (int p = 0; p < npairs; p++) {
-        const int nq = counts[pairs_qt[2 * p]];
-        for (int q = 0; q < kcap; q++) { idx[((size_t)p * kcap + q) * 2] = idx[((size_t)p * kcap + q) * 2 + 1] = -1;
-                                         dist[((size_t)p * kcap + q) * 2] = dist[((size_t)p * kcap + q) * 2 + 1] = -1; }
-        decode_rows(s->h_knn + (size_t)p * kcap, std::min(nq, kcap), idx + (size_t)p * kcap * 2, dist + (size_t)p * kcap * 2);
-    }
+    j.kind = Job::MATCH; j.nframes = nframes; j.dist_thresh = dist_thresh; j.ratio = ratio;
+    j.ext_desc = desc_dev; j.ext_counts = counts; j.ext_total = ntotal; j.ext_sets = sets;
+    const int st = r->rig.submit(slot, j);
+    return st != MCORB_OK ? st : r->rig.wait(slot);
+}
+
+int mcorb_rig_export_descriptors(mcorb_rig *r, int slot, void *dst_dev, int32_t *counts_host, int nimg)
+{
+    Slot *s = get_slot(r, slot);
+    if (!s) return MCORB_E_STATE;
+    if (!dst_dev || nimg < 1 || nimg > s->nimg_done) { set_error("export: bad argument"); return MCORB_E_ARG; }
+    HIPCHK(hipSetDevice(r->rig.device));
+    HIPCHK(hipMemcpyAsync(dst_dev, s->d_desc, (size_t)nimg * r->rig.geom.kcap * 32, hipMemcpyDeviceToDevice, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    if (counts_host) for (int m = 0; m < nimg; m++) counts_host[m] = s->h_nsel[m];
     return MCORB_OK;
 }
 
@@ -506,7 +507,7 @@ static int knn2_host_arrays(mcorb_t *e, const uint8_t *q, int nq, const uint8_t 
     e->h_counts[0] = nq;
     e->h_counts[1] = nt;
     e->h_pair[0] = int2{0, 1};
-    launch_knn2(nullptr, e->d_desc, e->h_counts, e->h_pair, 1, e->kc, e->d_part, thr, ratio, e->h_rows);
+    launch_knn2(nullptr, e->d_desc, e->h_counts, e->h_pair, 1, e->kc, e->d_part, thr, ratio, e->h_rows, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(nullptr));
     return MCORB_OK;
@@ -536,6 +537,49 @@ int mcorb_match_ratio(mcorb_t *e, const uint8_t *q, int nq, const uint8_t *t, in
     }
     if (n_out) *n_out = n;
     if (n > cap) { set_error("match buffer too small"); return MCORB_E_CAP; }
+    return MCORB_OK;
+}
+
+int mcorb_host_select(const uint32_t *packed, int n, int minX, int maxX, int minY, int maxY, int nfeatures_level,
+                      int32_t *out_idx, int cap)
+{
+    if (n < 0 || (n && !packed) || !out_idx) { set_error("host_select: bad argument"); return MCORB_E_ARG; }
+    if (n == 0) return 0;
+    SelectScratch sc;
+    std::vector<int> out((size_t)std::max(nfeatures_level, 0) + 64 + 8);
+    const int r = select_octree(packed, n, minX, maxX, minY, maxY, nfeatures_level, out.data(), sc);
+    if (r < 0) { set_error("host_select: level too tall"); return MCORB_E_SIZE; }
+    if (r > cap) { set_error("host_select: output too small"); return MCORB_E_CAP; }
+    for (int i = 0; i < r; i++) out_idx[i] = out[i];
+    return r;
+}
+
+int mcorb_host_resize_axis(int ssize, int dsize, int is_x, int32_t *quads)
+{
+    if (ssize < 1 || dsize < 1 || !quads) return MCORB_E_ARG;
+    std::vector<ResizeTap> t;
+    build_resize_axis(ssize, dsize, is_x != 0, t, 1);
+    for (int d = 0; d < dsize; d++) {
+        quads[4 * d] = t[d].s0; quads[4 * d + 1] = t[d].s1; quads[4 * d + 2] = t[d].c0; quads[4 * d + 3] = t[d].c1;
+    }
+    return MCORB_OK;
+}
+
+int mcorb_host_geometry(const mcorb_params *p, int w, int h, int32_t *six)
+{
+    if (!p || !six) return MCORB_E_ARG;
+    Tables t;
+    int st = compute_tables(*p, t);
+    if (st != MCORB_OK) return st;
+    Geom g;
+    std::vector<ResizeTap> taps;
+    st = build_geometry(*p, t, w, h, g, taps);
+    if (st != MCORB_OK) return st;
+    for (int l = 0; l < g.nlevels; l++) {
+        const LevelGeom &L = g.lv[l];
+        int32_t *o = six + 6 * l;
+        o[0] = L.w; o[1] = L.h; o[2] = L.nCols; o[3] = L.nRows; o[4] = L.wCell; o[5] = L.hCell;
+    }
     return MCORB_OK;
 }
 

@@ -167,7 +167,8 @@ int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g
     g.imgBytes = (uint32_t)(off + 256);
     g.kcap = (int)align_up((size_t)p.nfeatures + 4 * t.nlevels + 48, 64);
     if (g.kcap > 65535) { set_error("nfeatures too large (k-NN index is 16 bits)"); return MCORB_E_ARG; }
-    g.candCap = p.cand_cap > 0 ? p.cand_cap : 65536;
+    // default: one candidate slot per 4 level-0 pixels (measured: ~1 per 28 px on the synthetic rig frames)
+    g.candCap = p.cand_cap > 0 ? p.cand_cap : (int)align_up(std::max((size_t)65536, (size_t)W * H / 4), 4096);
     return MCORB_OK;
 }
 
@@ -462,15 +463,12 @@ void Rig::driver(Slot *sp)
             if (st == MCORB_OK) st = finish_match(s, j);
             break;
         case Job::MATCH:
-            if (j.ext_desc) st = run_external_knn(s, j);
-            else {
-                st = enqueue_match(s, j);
-                if (st == MCORB_OK) {
-                    hipError_t e = hipStreamSynchronize(s.st);
-                    if (e != hipSuccess) { set_error(hipGetErrorString(e)); st = MCORB_E_HIP; }
-                }
-                if (st == MCORB_OK) st = finish_match(s, j);
+            st = enqueue_match(s, j);
+            if (st == MCORB_OK) {
+                hipError_t e = hipStreamSynchronize(s.st);
+                if (e != hipSuccess) { set_error(hipGetErrorString(e)); st = MCORB_E_HIP; }
             }
+            if (st == MCORB_OK) st = finish_match(s, j);
             break;
         default: break;
         }
@@ -490,18 +488,19 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
     s.h_overflow[0] = 0;
     HIPCHK(hipEventRecord(s.ev[0], s.st));
     launch_pyramid(s.st, s.d_pyr, geom, d_taps, j.nimg);
-    launch_fast(s.st, s.d_pyr, geom, params.ini_th_fast, params.min_th_fast, s.d_cellkp, s.d_cellcnt, s.h_cand,
-                s.h_lvloff, s.h_overflow, j.nimg);
     HIPCHK(hipEventRecord(s.ev[1], s.st));
+    launch_fast(s.st, s.d_pyr, geom, params.ini_th_fast, params.min_th_fast, s.d_cellkp, s.d_cellcnt, s.h_cand,
+                s.h_lvloff, s.h_overflow, j.nimg, s.ev[2]);
+    HIPCHK(hipEventRecord(s.ev[3], s.st));
     launch_blur(s.st, s.d_pyr, s.d_blur, geom, j.nimg);
-    HIPCHK(hipEventRecord(s.ev[2], s.st));
+    HIPCHK(hipEventRecord(s.ev[4], s.st));
     HIPCHK(hipGetLastError());
     return MCORB_OK;
 }
 
 int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
 {
-    HIPCHK(hipEventSynchronize(s.ev[1]));
+    HIPCHK(hipEventSynchronize(s.ev[3]));
     if (s.h_overflow[0]) {
         set_error("FAST candidate buffer overflow (raise mcorb_params.cand_cap)");
         (void)hipStreamSynchronize(s.st);
@@ -566,12 +565,12 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     const auto t1 = std::chrono::steady_clock::now();
     s.timing[1] = std::chrono::duration<float, std::micro>(t1 - t0).count();
 
-    HIPCHK(hipEventRecord(s.ev[3], s.st));
+    HIPCHK(hipEventRecord(s.ev[5], s.st));
     launch_describe(s.st, s.d_pyr, s.d_blur, geom, s.h_sel, s.h_nsel, params.orientation, s.d_desc, s.d_angles, nimg);
     HIPCHK(hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)nimg * geom.kcap * 32, hipMemcpyDeviceToHost, s.st));
     if (params.orientation)
         HIPCHK(hipMemcpyAsync(s.h_angles, s.d_angles, (size_t)nimg * geom.kcap * sizeof(float), hipMemcpyDeviceToHost, s.st));
-    HIPCHK(hipEventRecord(s.ev[4], s.st));
+    HIPCHK(hipEventRecord(s.ev[6], s.st));
     s.nimg_done = nimg;
     if (then_match) TRY(enqueue_match(s, j));
     HIPCHK(hipGetLastError());
@@ -580,32 +579,54 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
         for (int m = 0; m < nimg; m++)
             for (size_t k = 0; k < s.kps[m].size(); k++) s.kps[m][k].angle = s.h_angles[(size_t)m * geom.kcap + k];
     s.nimg_done = nimg;
-    float a = 0, b = 0, c = 0;
-    (void)hipEventElapsedTime(&a, s.ev[0], s.ev[1]);
-    (void)hipEventElapsedTime(&b, s.ev[1], s.ev[2]);
-    (void)hipEventElapsedTime(&c, s.ev[3], s.ev[4]);
+    float a = 0, b = 0, c = 0, t = 0;
+    (void)hipEventElapsedTime(&a, s.ev[0], s.ev[3]);
+    (void)hipEventElapsedTime(&b, s.ev[3], s.ev[4]);
+    (void)hipEventElapsedTime(&c, s.ev[5], s.ev[6]);
     s.timing[0] = a * 1000.f;
     s.timing[2] = (b + c) * 1000.f;
+    (void)hipEventElapsedTime(&t, s.ev[0], s.ev[1]); s.timing[4] = t * 1000.f;   // pyramid launches
+    (void)hipEventElapsedTime(&t, s.ev[1], s.ev[2]); s.timing[5] = t * 1000.f;   // k_fast_cells
+    (void)hipEventElapsedTime(&t, s.ev[2], s.ev[3]); s.timing[6] = t * 1000.f;   // k_compact
     return MCORB_OK;
 }
 
 int Rig::enqueue_match(Slot &s, const Job &j)
 {
-    if (j.nframes < 1 || j.nframes > max_frames || j.nframes * ncams > s.nimg_done) {
+    const bool ext = j.ext_desc != nullptr;
+    if (j.nframes < 1 || j.nframes > max_frames || (!ext && j.nframes * ncams > s.nimg_done)) {
         set_error("match: bad frame count or features not extracted");
         return MCORB_E_STATE;
     }
-    if (npp == 0) { s.npairs_done = 0; s.nframes_done = j.nframes; return MCORB_OK; }
+    const int C = ncams;
+    s.match_external = ext;
+    s.match_sets.resize((size_t)j.nframes * C);
+    s.match_counts.resize((size_t)j.nframes * C);
+    if (ext) {
+        if (j.ext_total < 1 || j.ext_total > 4096 || !j.ext_counts || !j.ext_sets) { set_error("match: bad external block"); return MCORB_E_ARG; }
+        for (int i = 0; i < j.ext_total; i++) s.h_extcounts[i] = std::min(std::max(j.ext_counts[i], 0), geom.kcap);
+        for (int i = 0; i < j.nframes * C; i++) {
+            const int set = j.ext_sets[i];
+            if (set < 0 || set >= j.ext_total) { set_error("match: set index out of range"); return MCORB_E_ARG; }
+            s.match_sets[i] = set;
+            s.match_counts[i] = s.h_extcounts[set];
+        }
+    } else {
+        for (int i = 0; i < j.nframes * C; i++) { s.match_sets[i] = i; s.match_counts[i] = s.h_nsel[i]; }
+    }
+    s.nframes_done = j.nframes;
+    s.npairs_done = 0;
+    if (npp == 0) return MCORB_OK;
     int p = 0;
     for (int f = 0; f < j.nframes; f++)
-        for (int a = 0; a < ncams - 1; a++)
-            for (int b = a + 1; b < ncams; b++) s.h_pairs[p++] = int2{f * ncams + a, f * ncams + b};
-    HIPCHK(hipEventRecord(s.ev[5], s.st));
-    launch_knn2(s.st, s.d_desc, s.h_nsel, s.h_pairs, p, geom.kcap, s.d_part, j.dist_thresh, j.ratio, s.h_knn);
-    HIPCHK(hipEventRecord(s.ev[6], s.st));
+        for (int a = 0; a < C - 1; a++)
+            for (int b = a + 1; b < C; b++) s.h_pairs[p++] = int2{s.match_sets[f * C + a], s.match_sets[f * C + b]};
+    HIPCHK(hipEventRecord(s.ev[7], s.st));
+    launch_knn2(s.st, ext ? (const uint8_t *)j.ext_desc : s.d_desc, ext ? s.h_extcounts : s.h_nsel, s.h_pairs, p,
+                geom.kcap, s.d_part, j.dist_thresh, j.ratio, s.h_knn, s.ev[8]);
+    HIPCHK(hipEventRecord(s.ev[9], s.st));
     HIPCHK(hipGetLastError());
     s.npairs_done = p;
-    s.nframes_done = j.nframes;
     return MCORB_OK;
 }
 
@@ -613,19 +634,20 @@ int Rig::enqueue_match(Slot &s, const Job &j)
 // (MultiCameraFrame.cpp:1060-1078, 1167-1268), host side, after the k-NN tables landed.
 int Rig::finish_match(Slot &s, const Job &j)
 {
+    (void)j;
     const int C = ncams;
     for (int f = 0; f < s.nframes_done; f++) {
         std::vector<int32_t> &tr = s.tracks[f];
         tr.clear();
         int ntr = 0, mergeable = 0;
         std::vector<std::vector<int>> inv(C);
-        for (int c = 0; c < C; c++) inv[c].assign(s.kps[f * C + c].size(), -1);
+        for (int c = 0; c < C; c++) inv[c].assign(s.match_counts[f * C + c], -1);
         int pi = f * npp;
         for (int a = 0; a < C - 1; a++) {
             for (int b = a + 1; b < C; b++, pi++) {
                 std::vector<uint32_t> &i1 = s.m_idx1[pi], &i2 = s.m_idx2[pi];
                 i1.clear(); i2.clear();
-                const int nq = s.h_nsel[f * C + a];
+                const int nq = s.match_counts[f * C + a];
                 const KnnRow *rows = s.h_knn + (size_t)pi * geom.kcap;
                 for (int q = 0; q < nq; q++) {
                     const KnnRow &r = rows[q];
@@ -663,27 +685,9 @@ int Rig::finish_match(Slot &s, const Job &j)
     }
     if (s.npairs_done > 0) {
         float m = 0;
-        (void)hipEventElapsedTime(&m, s.ev[5], s.ev[6]);
-        s.timing[3] = m * 1000.f;
+        (void)hipEventElapsedTime(&m, s.ev[7], s.ev[9]); s.timing[3] = m * 1000.f;
+        (void)hipEventElapsedTime(&m, s.ev[7], s.ev[8]); s.timing[7] = m * 1000.f;   // k_knn2
     }
-    (void)j;
-    return MCORB_OK;
-}
-
-int Rig::run_external_knn(Slot &s, const Job &j)
-{
-    if (j.ext_total < 1 || j.ext_total > 4096 || j.ext_npairs < 1) { set_error("external knn: bad sizes"); return MCORB_E_ARG; }
-    const int nchunks = (geom.kcap + kKnnChunk - 1) / kKnnChunk;
-    const int npairs_max = std::max(1, npp * max_frames);
-    if (j.ext_npairs > npairs_max) { set_error("external knn: too many pairs for this rig's buffers"); return MCORB_E_CAP; }
-    (void)nchunks;
-    for (int i = 0; i < j.ext_total; i++) s.h_extcounts[i] = j.ext_counts[i];
-    for (int i = 0; i < j.ext_npairs; i++) s.h_pairs[i] = int2{j.ext_pairs[2 * i], j.ext_pairs[2 * i + 1]};
-    launch_knn2(s.st, (const uint8_t *)j.ext_desc, s.h_extcounts, s.h_pairs, j.ext_npairs, geom.kcap, s.d_part,
-                j.dist_thresh, j.ratio, s.h_knn);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s.st));
-    s.npairs_done = j.ext_npairs;
     return MCORB_OK;
 }
 

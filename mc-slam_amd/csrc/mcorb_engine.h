@@ -66,12 +66,12 @@ struct Job {
     enum Kind { NONE, EXTRACT, MATCH, PROCESS } kind = NONE;
     int nimg = 0, nframes = 0, lap0 = 0, lap1 = 0;
     float dist_thresh = 75.f, ratio = 0.85f;
-    // external k-NN (RCCL path)
+    // external descriptor block (RCCL path): ext_total sets of [kcap][32] bytes on the device,
+    // ext_counts[set] descriptors each; ext_sets[f*ncams + c] = set holding camera c of frame f
     const void *ext_desc = nullptr;
     const int32_t *ext_counts = nullptr;
     int ext_total = 0;
-    const int32_t *ext_pairs = nullptr;
-    int ext_npairs = 0;
+    const int32_t *ext_sets = nullptr;
 };
 
 class Rig;
@@ -80,7 +80,7 @@ struct Slot {
     Rig *rig = nullptr;
     int index = 0;
     hipStream_t st = nullptr;
-    hipEvent_t ev[8] = {};   // 0 A-start, 1 FAST done, 2 blur done, 3/4 describe, 5/6 match
+    hipEvent_t ev[12] = {};  // 0 start, 1 pyramid done, 2 FAST done, 3 compact done, 4 blur done, 5/6 describe(+D2H), 7 knn2 start, 8 knn2 done, 9 finalize done
     // device
     uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_desc = nullptr;
     uint32_t *d_cellkp = nullptr;
@@ -107,7 +107,9 @@ struct Slot {
     std::vector<std::vector<uint32_t>> m_idx1, m_idx2;   // per pair
     std::vector<std::vector<int32_t>> tracks;            // per frame, ncams ints per track
     std::vector<int> mergeable;
-    float timing[4] = {0, 0, 0, 0};
+    float timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<int> match_sets, match_counts;   // per (frame, cam) of the last match: set index, descriptor count
+    bool match_external = false;
     // driver thread
     std::thread th;
     std::mutex m;
@@ -146,7 +148,6 @@ private:
     int run_select_and_describe(Slot &s, const Job &j, bool then_match);
     int enqueue_match(Slot &s, const Job &j);
     int finish_match(Slot &s, const Job &j);
-    int run_external_knn(Slot &s, const Job &j);
 };
 
 }  // namespace mcorb

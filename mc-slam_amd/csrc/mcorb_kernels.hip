@@ -563,10 +563,11 @@ void launch_pyramid(hipStream_t st, uint8_t *pyr, const Geom &g, const ResizeTap
 }
 
 void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, uint32_t *cell_kp,
-                 int *cell_cnt, uint32_t *cand, int *lvl_off, int *overflow, int nimg)
+                 int *cell_cnt, uint32_t *cand, int *lvl_off, int *overflow, int nimg, hipEvent_t ev_mid)
 {
     dim3 grid(g.cells, nimg);
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, st, pyr, g, iniTh, minTh, cell_kp, cell_cnt);
+    if (ev_mid) (void)hipEventRecord(ev_mid, st);
     hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, st, cell_kp, cell_cnt, g, cand, lvl_off, overflow);
 }
 
@@ -584,11 +585,12 @@ void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, co
 }
 
 void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const int2 *pairs, int npairs, int kcap,
-                 uint2 *part, float dist_thresh, float ratio, KnnRow *out)
+                 uint2 *part, float dist_thresh, float ratio, KnnRow *out, hipEvent_t ev_mid)
 {
     const int nchunks = (kcap + kKnnChunk - 1) / kKnnChunk;
     dim3 grid((kcap + 63) / 64, nchunks, npairs);
     hipLaunchKernelGGL(k_knn2, grid, dim3(64), 0, st, desc, counts, pairs, kcap, nchunks, part);
+    if (ev_mid) (void)hipEventRecord(ev_mid, st);
     dim3 g2((kcap + 255) / 256, npairs);
     hipLaunchKernelGGL(k_knn2_finalize, g2, dim3(256), 0, st, part, counts, pairs, kcap, nchunks, dist_thresh, ratio, out);
 }

@@ -1,0 +1,129 @@
+"""Host-side stages of the product (tables, geometry, resize coefficient tables, quad-tree
+selection, Hamming helper, synthetic generator) against the oracle.  No GPU needed."""
+import ctypes as C
+from importlib import import_module
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pkg = import_module("mc-slam_amd")
+_lib = pkg._lib
+L = _lib.load()
+
+
+@pytest.mark.parametrize("nfeat,sf,nl", [(2000, 1.2, 8), (1000, 1.2, 8), (500, 1.5, 4), (3000, 1.1, 12), (300, 1.2, 1)])
+def test_tables_match_oracle(nfeat, sf, nl):
+    p = _lib.default_params(nfeatures=nfeat, scale_factor=sf, nlevels=nl)
+    mine = pkg.get_tables(p)
+    ref = O.OracleExtractor(nfeat, sf, nl).tables()
+    for k in ("scale", "inv_scale", "sigma2", "inv_sigma2", "quota"):
+        assert np.array_equal(mine[k], ref[k]), k
+
+
+@pytest.mark.parametrize("w,h", [(640, 480), (1280, 720), (1920, 1080), (752, 480), (1241, 376)])
+def test_geometry_matches_reference_arithmetic(w, h):
+    p = _lib.default_params()
+    six = np.zeros((8, 6), np.int32)
+    assert L.mcorb_host_geometry(C.byref(p), w, h, six.ctypes.data) == 0
+    ex = O.OracleExtractor()
+    for l in range(8):
+        lw, lh = ex.level_size(l, w, h)
+        assert (six[l, 0], six[l, 1]) == (lw, lh)
+        width, height = np.float32(lw - 32), np.float32(lh - 32)          # ORBextractor.cpp:796-802
+        ncols, nrows = int(width / np.float32(35)), int(height / np.float32(35))
+        assert (six[l, 2], six[l, 3]) == (ncols, nrows)
+        assert six[l, 4] == int(np.ceil(width / ncols)) and six[l, 5] == int(np.ceil(height / nrows))
+
+
+def test_geometry_rejects_sizes_the_reference_cannot_handle():
+    p = _lib.default_params()
+    six = np.zeros((8, 6), np.int32)
+    assert L.mcorb_host_geometry(C.byref(p), 160, 120, six.ctypes.data) == _lib.E_SIZE    # level 7 narrower than a cell
+    assert L.mcorb_host_geometry(C.byref(p), 480, 1400, six.ctypes.data) == _lib.E_SIZE   # nIni = round(w/h) = 0
+
+
+@pytest.mark.parametrize("ssize,dsize", [(1280, 1067), (720, 600), (1067, 889), (640, 533), (357, 298), (201, 168), (50, 50), (7, 20)])
+def test_resize_axis_tables_match_oracle(ssize, dsize):
+    ofs, coef = O.resize_tables(ssize, dsize)             # x axis (clamped), as cv::resize builds it
+    q = np.zeros((dsize, 4), np.int32)
+    assert L.mcorb_host_resize_axis(ssize, dsize, 1, q.ctypes.data) == 0
+    assert np.array_equal(q[:, 0], ofs)
+    tail = ofs + 1 >= ssize
+    assert np.array_equal(q[~tail, 2:], coef[~tail].astype(np.int32))
+    assert np.all(q[tail, 2] == 2048) and np.all(q[tail, 3] == 0)        # HResizeLinear tail: S[sx]*ONE
+    assert np.all(q[:, 1] == np.minimum(ofs + 1, ssize - 1))
+
+
+def _pack(x, y, r):
+    return (y.astype(np.uint32) << 20) | (x.astype(np.uint32) << 8) | r.astype(np.uint32)
+
+
+def _select(x, y, r, W, H, N):
+    packed = _pack(x, y, r)
+    out = np.zeros(N + 80, np.int32)
+    n = L.mcorb_host_select(packed.ctypes.data, len(packed), 16, W - 16, 16, H - 16, N, out.ctypes.data, len(out))
+    return n, out[:max(n, 0)]
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("W,H,N,npts", [(640, 480, 217, 3000), (1280, 720, 434, 9000), (357, 201, 122, 900),
+                                        (300, 300, 50, 40), (640, 480, 5, 700)])
+def test_selection_stage_matches_oracle_on_random_candidates(seed, W, H, N, npts):
+    rng = np.random.default_rng(seed * 7 + N)
+    cells = rng.permutation((W - 32) * (H - 32))[:npts]
+    x = (cells % (W - 32)).astype(np.int32)
+    y = (cells // (W - 32)).astype(np.int32)
+    order = np.lexsort((x, y))                              # any fixed order; ties in response are common
+    x, y = x[order], y[order]
+    r = rng.integers(7, 60, npts).astype(np.int32)
+    n_o, idx_o = O.distribute_octree(x.astype(np.float32), y.astype(np.float32), r.astype(np.float32),
+                                     16, W - 16, 16, H - 16, N)
+    n_p, idx_p = _select(x, y, r, W, H, N)
+    assert n_p == n_o
+    assert np.array_equal(idx_p, idx_o), "selection differs in content or ORDER"
+
+
+def test_selection_stage_on_real_fast_candidates():
+    synth = import_module("mc-slam_amd.synth")
+    img = synth.synth_rig_frame_numpy(1, 2, 1, 640, 480)
+    ex = O.OracleExtractor(1000)
+    ex(img)
+    t = ex.tables()
+    for l in range(8):
+        x, y, r = ex.candidates(l)
+        lw, lh = ex.level_size(l, 640, 480)
+        n_o, idx_o = O.distribute_octree(x, y, r, 16, lw - 16, 16, lh - 16, int(t["quota"][l]))
+        n_p, idx_p = _select(x.astype(np.int32), y.astype(np.int32), r.astype(np.int32), lw, lh, int(t["quota"][l]))
+        assert n_p == n_o and np.array_equal(idx_p, idx_o), "level %d" % l
+
+
+def test_selection_edge_cases():
+    assert L.mcorb_host_select(None, 0, 16, 600, 16, 400, 10, np.zeros(4, np.int32).ctypes.data, 4) == 0
+    x = np.array([5], np.int32); y = np.array([7], np.int32); r = np.array([30], np.int32)
+    n, idx = _select(x, y, r, 640, 480, 100)
+    assert n == 1 and idx.tolist() == [0]
+    # too tall a level -> the reference has no root node
+    out = np.zeros(8, np.int32)
+    p = _pack(x, y, r)
+    assert L.mcorb_host_select(p.ctypes.data, 1, 16, 116, 16, 416, 10, out.ctypes.data, 8) == _lib.E_SIZE
+
+
+def test_hamming256_matches_reference_swar():
+    rng = np.random.default_rng(0)
+    for _ in range(100):
+        a = rng.integers(0, 256, 32, dtype=np.uint8)
+        b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert pkg.hamming256(a, b) == O.descriptor_distance(a, b)
+
+
+@pytest.mark.parametrize("w,h,nc", [(320, 240, 2), (640, 480, 4), (200, 150, 1)])
+def test_synthetic_generator_c_equals_numpy(w, h, nc):
+    for f in (0, 3):
+        for c in range(nc):
+            assert np.array_equal(pkg.synth_rig_frame(f, nc, c, w, h), pkg.synth_rig_frame_numpy(f, nc, c, w, h))
+    # cameras are horizontal-disparity crops of one canvas
+    a, b = pkg.synth_rig_frame(0, nc, 0, w, h), pkg.synth_rig_frame(0, max(nc, 2), 1, w, h)
+    if nc >= 2:
+        assert np.array_equal(a[:, 24:], b[:, :-24])
