@@ -207,12 +207,15 @@ int mcorb_match_ratio(mcorb_t *e, const uint8_t *q, int nq, const uint8_t *t, in
 /* ------------------------------------------------------------------------- */
 /* Host stages exposed for the CPU test-suite (no device needed)              */
 /* ------------------------------------------------------------------------- */
-/* The engine's quad-tree selection stage, DistributeOctTree's equivalent
- * (ORBextractor.cpp:554-778): packed candidates (y<<20 | x<<8 | response, x/y
- * relative to minBorder) in vToDistributeKeys order -> indices of the retained
- * candidates in result order.  Returns the count, MCORB_E_SIZE, or MCORB_E_CAP. */
+/* The engine's quad-tree selection, DistributeOctTree's equivalent (ORBextractor.cpp:554-778), run
+ * end to end on the host: the candidate bucketing that k_compact performs on the device is
+ * restated on the CPU, then the host tree logic runs on it.  packed = (y<<20 | x<<8 | response),
+ * x/y relative to minBorder; wCell/hCell = cell grid of the detection loop, from which the
+ * reference's "first maximum wins" order (cell row, cell col, y, x) is recovered (pass 0,0 when
+ * the candidates are in plain raster order).  out_idx receives indices into `packed` in result
+ * order.  Returns the count, MCORB_E_SIZE, or MCORB_E_CAP. */
 int mcorb_host_select(const uint32_t *packed, int n, int minX, int maxX, int minY, int maxY,
-                      int nfeatures_level, int32_t *out_idx, int cap);
+                      int nfeatures_level, int wCell, int hCell, int32_t *out_idx, int cap);
 /* The engine's cv::resize coefficient table for one axis: per destination index
  * (s0, s1, c0, c1) as int32 quadruples (x axis: clamped per HResizeLinear; y axis:
  * row indices clipped, fraction kept). */

@@ -78,7 +78,7 @@ SIGNATURES = {
     "mcorb_hamming256": (_i, [_vp, _vp]),
     "mcorb_knn2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "mcorb_match_ratio": (_i, [_vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _i, _ip]),
-    "mcorb_host_select": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i]),
+    "mcorb_host_select": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i]),
     "mcorb_host_resize_axis": (_i, [_i, _i, _i, _vp]),
     "mcorb_host_geometry": (_i, [C.POINTER(Params), _i, _i, _vp]),
     "mcorb_synth_rig_frame": (_i, [C.c_uint32, _i, _i, _i, _i, _vp, _i]),

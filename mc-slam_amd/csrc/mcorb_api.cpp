@@ -2,6 +2,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <new>
 
 #include "mcorb_engine.h"
@@ -197,10 +198,10 @@ static void decode_rows(const KnnRow *rows, int nq, int32_t *idx, int32_t *dist)
 {
     for (int q = 0; q < nq; q++) {
         const KnnRow &k = rows[q];
-        idx[2 * q] = k.idx0;
-        dist[2 * q] = k.d0;
-        idx[2 * q + 1] = k.idx1;
-        dist[2 * q + 1] = k.idx1 < 0 ? -1 : (k.d1 & 0x3fffffff);
+        idx[2 * q] = knn_idx0(k);
+        dist[2 * q] = knn_d0(k);
+        idx[2 * q + 1] = knn_idx1(k);
+        dist[2 * q + 1] = knn_d1(k);
     }
 }
 
@@ -275,7 +276,19 @@ int mcorb_rig_get_candidates(mcorb_rig *r, int slot, int m, int level, uint32_t 
     const int n = lo[level + 1] - lo[level];
     if (n_out) *n_out = n;
     if (n > cap) { set_error("candidate buffer too small"); return MCORB_E_CAP; }
-    if (n) memcpy(packed, s->h_cand + (size_t)m * g.candCap + lo[level], (size_t)n * 4);
+    if (n) {
+        // the device hands candidates over bucketed by quad-tree path; restore vToDistributeKeys order
+        // (cell row, cell col, y, x) for the caller
+        const uint32_t *src = s->h_cand + (size_t)m * g.candCap + lo[level];
+        const int wc = g.lv[level].wCell, hc = g.lv[level].hCell;
+        std::vector<std::pair<uint64_t, uint32_t>> v(n);
+        for (int i = 0; i < n; i++) {
+            const int x = cand_x(src[i]), y = cand_y(src[i]);
+            v[i] = {((((uint64_t)((y - 3) / hc) << 12 | (uint64_t)((x - 3) / wc)) << 12 | (uint64_t)y) << 12) | (uint64_t)x, src[i]};
+        }
+        std::sort(v.begin(), v.end());
+        for (int i = 0; i < n; i++) packed[i] = v[i].second;
+    }
     return MCORB_OK;
 }
 
@@ -530,8 +543,8 @@ int mcorb_match_ratio(mcorb_t *e, const uint8_t *q, int nq, const uint8_t *t, in
     int n = 0;
     for (int i = 0; i < nq; i++) {
         const KnnRow &r = e->h_rows[i];
-        if (r.idx1 >= 0 && ((r.d1 >> 30) & 1)) {
-            if (n < cap) { idx1[n] = (uint32_t)i; idx2[n] = (uint32_t)r.idx0; }
+        if (knn_accept(r)) {
+            if (n < cap) { idx1[n] = (uint32_t)i; idx2[n] = (uint32_t)knn_idx0(r); }
             n++;
         }
     }
@@ -541,17 +554,40 @@ int mcorb_match_ratio(mcorb_t *e, const uint8_t *q, int nq, const uint8_t *t, in
 }
 
 int mcorb_host_select(const uint32_t *packed, int n, int minX, int maxX, int minY, int maxY, int nfeatures_level,
-                      int32_t *out_idx, int cap)
+                      int wCell, int hCell, int32_t *out_idx, int cap)
 {
     if (n < 0 || (n && !packed) || !out_idx) { set_error("host_select: bad argument"); return MCORB_E_ARG; }
     if (n == 0) return 0;
-    SelectScratch sc;
+    const SelectParams P = make_select_params(minX, maxX, minY, maxY, nfeatures_level, wCell, hCell);
+    if (P.nIni < 1) { set_error("host_select: level too tall"); return MCORB_E_SIZE; }
+    static thread_local SelectScratch sc;
+    std::vector<uint32_t> sorted;
+    std::vector<int> perm, bstart;
+    host_bucket_sort(packed, n, P, sorted, perm, bstart);   // what k_compact does on the device
     std::vector<int> out((size_t)std::max(nfeatures_level, 0) + 64 + 8);
-    const int r = select_octree(packed, n, minX, maxX, minY, maxY, nfeatures_level, out.data(), sc);
+    const int r = select_octree(sorted.data(), bstart.data(), n, P, out.data(), sc);
     if (r < 0) { set_error("host_select: level too tall"); return MCORB_E_SIZE; }
     if (r > cap) { set_error("host_select: output too small"); return MCORB_E_CAP; }
-    for (int i = 0; i < r; i++) out_idx[i] = out[i];
+    for (int i = 0; i < r; i++) out_idx[i] = perm[out[i]];
     return r;
+}
+
+// development aid (not part of the public header): time the two halves of mcorb_host_select
+int mcorb_dev_select_timing(const uint32_t *packed, int n, int minX, int maxX, int minY, int maxY, int N, int wCell,
+                            int hCell, int reps, double *us_sort, double *us_select)
+{
+    const SelectParams P = make_select_params(minX, maxX, minY, maxY, N, wCell, hCell);
+    static thread_local SelectScratch sc;
+    std::vector<uint32_t> sorted; std::vector<int> perm, bstart; std::vector<int> out((size_t)N + 80);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < reps; r++) host_bucket_sort(packed, n, P, sorted, perm, bstart);
+    auto t1 = std::chrono::steady_clock::now();
+    int m = 0;
+    for (int r = 0; r < reps; r++) m = select_octree(sorted.data(), bstart.data(), n, P, out.data(), sc);
+    auto t2 = std::chrono::steady_clock::now();
+    *us_sort = std::chrono::duration<double, std::micro>(t1 - t0).count() / reps;
+    *us_select = std::chrono::duration<double, std::micro>(t2 - t1).count() / reps;
+    return m;
 }
 
 int mcorb_host_resize_axis(int ssize, int dsize, int is_x, int32_t *quads)

@@ -10,6 +10,7 @@ constexpr int kEdge = 19;          // EDGE_THRESHOLD, ORBextractor.cpp:72
 constexpr int kMinBorder = 16;     // EDGE_THRESHOLD-3, ORBextractor.cpp:788
 constexpr int kCellW = 35;         // W, ORBextractor.cpp:784
 constexpr int kMaxRoi = 76;        // wCell < 70 by construction, +6 overlap
+constexpr int kBlurTW = 128, kBlurTH = 32;   // blur output tile per workgroup
 constexpr int kTilePitch = 80;     // LDS pitch of a FAST cell tile (3 phase bytes + 76, multiple of 4)
 
 // Packed FAST candidate: y (12 bits, relative to minBorder) | x (12 bits) | response (8 bits).
@@ -28,10 +29,16 @@ struct LevelGeom {
     int nCols, nRows;    // cell grid (ORBextractor.cpp:799-800)
     int wCell, hCell;    // (:801-802)
     int cell0;           // index of this level's first cell inside one image
-    int tile0;           // index of this level's first 64x16 blur tile inside one image
+    int tile0;           // index of this level's first blur tile inside one image
     int tilesX, tilesY;
     int maxBorderX, maxBorderY;   // (:790-791)
     uint32_t xtab, ytab; // element offsets into the resize tables (levels >= 1)
+    // quad-tree bucketing of the FAST candidates (DistributeOctTree's first `depth` splits)
+    int nIni;            // root nodes, round(width/height) (ORBextractor.cpp:558)
+    float hX;            // root width (:560)
+    int depth;           // path-code depth D: buckets = nIni * 4^D
+    int nBuckets;
+    int bucket0;         // index of this level's first bucket-start entry inside one image (nBuckets+1 entries)
 };
 
 struct Geom {
@@ -42,8 +49,37 @@ struct Geom {
     uint32_t imgBytes;    // bytes of one image's pyramid block
     int kcap;             // keypoint capacity per image
     int candCap;          // candidate capacity per image
+    int bucketTotal;      // bucket-start entries per image, all levels
     LevelGeom lv[kMaxLevels];
 };
+
+// Quad-tree path of a candidate: root node, then `depth` DivideNode splits
+// (ExtractorNode::DivideNode, ORBextractor.cpp:479-535: halfX = ceil((UR.x-UL.x)/2), children
+// n1..n4 = (x<split,y<split), (x>=,y<), (x<,y>=), (x>=,y>=)).  Candidates with equal codes are
+// exactly the key set of one tree node at that depth, whatever order the tree is expanded in.
+__host__ __device__ inline uint32_t path_code(int x, int y, int W0, int H0, int nIni, float hX, int depth)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int r = (int)__fdiv_rn((float)x, hX);                  // vpIniNodes[kp.pt.x/hX] (:584)
+    if (r >= nIni) r = nIni - 1;
+    int x0 = (int)__fmul_rn(hX, (float)r), x1 = (int)__fmul_rn(hX, (float)(r + 1));   // (:570-571)
+#else
+    int r = (int)((float)x / hX);
+    if (r >= nIni) r = nIni - 1;
+    int x0 = (int)(hX * (float)r), x1 = (int)(hX * (float)(r + 1));
+#endif
+    int y0 = 0, y1 = H0;
+    (void)W0;
+    uint32_t code = (uint32_t)r;
+    for (int d = 0; d < depth; d++) {
+        const int sx = x0 + ((x1 - x0 + 1) >> 1), sy = y0 + ((y1 - y0 + 1) >> 1);
+        const int qx = x >= sx, qy = y >= sy;
+        if (qx) x0 = sx; else x1 = sx;
+        if (qy) y0 = sy; else y1 = sy;
+        code = (code << 2) | (uint32_t)(qx + 2 * qy);
+    }
+    return code;
+}
 
 // resize table entries (built on the host exactly as cv::resize builds xofs/ialpha, yofs/ibeta)
 struct ResizeTap { uint16_t s0, s1; int16_t c0, c1; };

@@ -120,7 +120,7 @@ int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g
     taps.clear();
     g.nlevels = t.nlevels;
     size_t off = 0;
-    int cells = 0, tiles = 0, cellCap = 4;
+    int cells = 0, tiles = 0, cellCap = 4, buckets = 0;
     for (int l = 0; l < t.nlevels; l++) {
         LevelGeom &L = g.lv[l];
         const float sc = t.inv_scale[l];
@@ -138,19 +138,26 @@ int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g
         }
         L.wCell = (int)ceilf(width / L.nCols);
         L.hCell = (int)ceilf(height / L.nRows);
-        const int nIni = (int)roundf((float)(L.maxBorderX - kMinBorder) / (L.maxBorderY - kMinBorder));
-        if (nIni < 1) {
+        const SelectParams sp = make_select_params(kMinBorder, L.maxBorderX, kMinBorder, L.maxBorderY, t.quota[l], 1, 1);
+        if (sp.nIni < 1) {
             set_error("image too tall: DistributeOctTree would have no root node");
             return MCORB_E_SIZE;
         }
+        if (sp.nIni > 16) { set_error("image too wide (more than 16 root nodes)"); return MCORB_E_SIZE; }
+        L.nIni = sp.nIni;
+        L.hX = sp.hX;
+        L.depth = sp.depth;
+        L.nBuckets = sp.nIni << (2 * sp.depth);
+        L.bucket0 = buckets;
+        buckets += L.nBuckets + 1;
         if (L.w > 4096 || L.h > 4096) { set_error("image larger than 4096 px"); return MCORB_E_SIZE; }
         L.pitch = (int)align_up((size_t)L.w, 64);
         L.off = (uint32_t)off;
         off += align_up((size_t)L.pitch * L.h, 256);
         L.cell0 = cells;
         cells += L.nCols * L.nRows;
-        L.tilesX = (L.w + 63) / 64;
-        L.tilesY = (L.h + 15) / 16;
+        L.tilesX = (L.w + kBlurTW - 1) / kBlurTW;
+        L.tilesY = (L.h + kBlurTH - 1) / kBlurTH;
         L.tile0 = tiles;
         tiles += L.tilesX * L.tilesY;
         cellCap = std::max(cellCap, ((L.wCell + 1) / 2) * ((L.hCell + 1) / 2));
@@ -163,6 +170,7 @@ int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g
     }
     g.cells = cells;
     g.tiles = tiles;
+    g.bucketTotal = buckets;
     g.cellCap = (int)align_up((size_t)cellCap, 4);
     g.imgBytes = (uint32_t)(off + 256);
     g.kcap = (int)align_up((size_t)p.nfeatures + 4 * t.nlevels + 48, 64);
@@ -194,13 +202,26 @@ void WorkerPool::run(int widx)
         Batch *b = nullptr;
         {
             std::unique_lock<std::mutex> lk(m_);
+            // spin briefly before sleeping: batches arrive every few hundred microseconds when the
+            // pipeline is busy, and a futex wake-up costs more than the selection of one image
+            if (queue_.empty() && !stop_) {
+                lk.unlock();
+                const auto t0 = std::chrono::steady_clock::now();
+                while (pending_.load(std::memory_order_acquire) == 0 &&
+                       std::chrono::steady_clock::now() - t0 < std::chrono::microseconds(150)) {
+                    __builtin_ia32_pause();
+                }
+                lk.lock();
+            }
             cv_.wait(lk, [this] { return stop_ || !queue_.empty(); });
             if (stop_ && queue_.empty()) return;
             b = queue_.front();
             if (b->next.load() >= b->n) {   // exhausted: drop it from the queue
                 queue_.erase(queue_.begin());
+                pending_.fetch_sub(1, std::memory_order_acq_rel);
                 continue;
             }
+            b->refs.fetch_add(1, std::memory_order_acq_rel);   // the batch lives on its submitter's stack
         }
         for (;;) {
             const int t = b->next.fetch_add(1);
@@ -211,6 +232,7 @@ void WorkerPool::run(int widx)
                 b->cv.notify_all();
             }
         }
+        b->refs.fetch_sub(1, std::memory_order_acq_rel);
     }
 }
 void WorkerPool::parallel_for(int n, const std::function<void(int, int)> &fn)
@@ -222,15 +244,22 @@ void WorkerPool::parallel_for(int n, const std::function<void(int, int)> &fn)
     {
         std::lock_guard<std::mutex> lk(m_);
         queue_.push_back(&b);
+        pending_.fetch_add(1, std::memory_order_acq_rel);
     }
     cv_.notify_all();
     {
         std::unique_lock<std::mutex> lk(b.m);
         b.cv.wait(lk, [&b] { return b.done.load() >= b.n; });
     }
-    // make sure no worker still holds the pointer through the queue
-    std::lock_guard<std::mutex> lk(m_);
-    queue_.erase(std::remove(queue_.begin(), queue_.end(), &b), queue_.end());
+    {
+        std::lock_guard<std::mutex> lk(m_);   // after this no new worker can pick the batch up
+        auto it = std::find(queue_.begin(), queue_.end(), &b);
+        if (it != queue_.end()) {
+            queue_.erase(it);
+            pending_.fetch_sub(1, std::memory_order_acq_rel);
+        }
+    }
+    while (b.refs.load(std::memory_order_acquire) != 0) std::this_thread::yield();   // workers still leaving the task loop
 }
 
 // ---------------------------------------------------------------------------
@@ -281,14 +310,35 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     TRY(compute_tables(p, tab));
     std::vector<ResizeTap> taps;
     TRY(build_geometry(p, tab, W, H, geom, taps));
+    for (int l = 0; l < geom.nlevels; l++)
+        selp[l] = make_select_params(kMinBorder, geom.lv[l].maxBorderX, kMinBorder, geom.lv[l].maxBorderY, tab.quota[l],
+                                     geom.lv[l].wCell, geom.lv[l].hCell);
     if (taps.empty()) taps.push_back(ResizeTap{0, 0, 0, 0});
+    // LDS source window of one resize workgroup (256 x 4 outputs): widest column span / tallest row span per level
+    for (int l = 1; l < geom.nlevels; l++) {
+        const LevelGeom &D = geom.lv[l];
+        int maxc = 4, maxr = 2;
+        for (int bx0 = 0; bx0 < D.w; bx0 += 256) {
+            const int bx1 = std::min(bx0 + 255, D.w - 1);
+            const int a = taps[D.xtab + bx0].s0 & ~3, b = taps[D.xtab + bx1].s1;
+            maxc = std::max(maxc, ((b - a) / 4 + 1) * 4);
+        }
+        for (int by0 = 0; by0 < D.h; by0 += 4) {
+            const int by1 = std::min(by0 + 3, D.h - 1);
+            maxr = std::max(maxr, (int)taps[D.ytab + by1].s1 - (int)taps[D.ytab + by0].s0 + 1);
+        }
+        resize_win[2 * l] = maxc;
+        resize_win[2 * l + 1] = maxr;
+        if ((size_t)maxc * maxr > 60000) { set_error("scale factor too large for the resize window"); return MCORB_E_ARG; }
+    }
     TRY(dev_alloc(&d_taps, taps.size()));
     HIPCHK(hipMemcpy(d_taps, taps.data(), taps.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
     HIPCHK(upload_umax(tab.umax));
 
     int nthreads = p.host_threads > 0 ? p.host_threads : (int)std::thread::hardware_concurrency();
     if (nthreads < 1) nthreads = 1;
-    if (p.host_threads <= 0) nthreads = std::min(nthreads, std::max(1, max_images * 2));
+    // default: one worker per image of a batch, at most 16 (the CPU share that goes with one GPU)
+    if (p.host_threads <= 0) nthreads = std::min(nthreads, std::max(2, std::min(max_images, 16)));
     nthreads = std::min(nthreads, 64);
     pool = new WorkerPool(nthreads);
     for (int i = 0; i < nthreads; i++) scratch.push_back(new SelectScratch);
@@ -301,6 +351,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         s->rig = this;
         s->index = si;
         HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&s->st_copy, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&s->st_dma, hipStreamNonBlocking));
         for (auto &e : s->ev) HIPCHK(hipEventCreate(&e));
         const size_t M = (size_t)max_images;
         TRY(dev_alloc(&s->d_pyr, M * geom.imgBytes));
@@ -309,6 +361,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         HIPCHK(hipMemset(s->d_blur, 0, M * geom.imgBytes));
         TRY(dev_alloc(&s->d_cellkp, M * geom.cells * geom.cellCap));
         TRY(dev_alloc(&s->d_cellcnt, M * geom.cells));
+        TRY(dev_alloc(&s->d_sorted, M * geom.candCap));
+        TRY(host_alloc(&s->h_bstart, M * geom.bucketTotal));
         TRY(dev_alloc(&s->d_desc, M * geom.kcap * 32));
         HIPCHK(hipMemset(s->d_desc, 0, M * geom.kcap * 32));
         TRY(dev_alloc(&s->d_angles, M * geom.kcap));
@@ -316,11 +370,21 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         TRY(host_alloc(&s->h_cand, M * geom.candCap));
         TRY(host_alloc(&s->h_lvloff, M * (kMaxLevels + 1)));
         TRY(host_alloc(&s->h_overflow, 16));
-        TRY(host_alloc(&s->h_sel, M * geom.kcap));
-        TRY(host_alloc(&s->h_nsel, M));
         TRY(host_alloc(&s->h_knn, (size_t)npairs_max * geom.kcap));
-        TRY(host_alloc(&s->h_pairs, (size_t)npairs_max));
-        TRY(host_alloc(&s->h_extcounts, 4096));
+        {
+            const size_t o_nsel = 4096 * sizeof(int);
+            const size_t o_pairs = align_up(o_nsel + M * sizeof(int), 64);
+            const size_t o_sel = align_up(o_pairs + (size_t)npairs_max * sizeof(int2), 64);
+            s->ctrl_pairs_end = o_sel;
+            s->ctrl_bytes = o_sel + M * geom.kcap * sizeof(uint32_t);
+            TRY(host_alloc(&s->h_ctrl, s->ctrl_bytes));
+            TRY(dev_alloc(&s->d_ctrl, s->ctrl_bytes));
+            HIPCHK(hipMemset(s->d_ctrl, 0, s->ctrl_bytes));
+            s->h_extcounts = (int *)s->h_ctrl;            s->d_extcounts = (int *)s->d_ctrl;
+            s->h_nsel = (int *)(s->h_ctrl + o_nsel);      s->d_nsel = (int *)(s->d_ctrl + o_nsel);
+            s->h_pairs = (int2 *)(s->h_ctrl + o_pairs);   s->d_pairs = (int2 *)(s->d_ctrl + o_pairs);
+            s->h_sel = (uint32_t *)(s->h_ctrl + o_sel);   s->d_sel = (uint32_t *)(s->d_ctrl + o_sel);
+        }
         TRY(host_alloc(&s->h_stage, M * (size_t)W * H));
         TRY(host_alloc(&s->h_desc, M * geom.kcap * 32));
         TRY(host_alloc(&s->h_angles, M * geom.kcap));
@@ -349,14 +413,18 @@ Rig::~Rig()
         }
         (void)hipSetDevice(device);
         if (s->st) (void)hipStreamSynchronize(s->st);
+        if (s->st_copy) (void)hipStreamSynchronize(s->st_copy);
+        if (s->st_dma) (void)hipStreamSynchronize(s->st_dma);
         (void)hipFree(s->d_pyr); (void)hipFree(s->d_blur); (void)hipFree(s->d_desc); (void)hipFree(s->d_cellkp);
-        (void)hipFree(s->d_cellcnt); (void)hipFree(s->d_angles); (void)hipFree(s->d_part); (void)hipFree(s->d_f32);
+        (void)hipFree(s->d_cellcnt); (void)hipFree(s->d_sorted); (void)hipHostFree(s->h_bstart); (void)hipFree(s->d_angles); (void)hipFree(s->d_part); (void)hipFree(s->d_f32);
         (void)hipHostFree(s->h_cand); (void)hipHostFree(s->h_lvloff); (void)hipHostFree(s->h_overflow);
-        (void)hipHostFree(s->h_sel); (void)hipHostFree(s->h_nsel); (void)hipHostFree(s->h_knn);
-        (void)hipHostFree(s->h_pairs); (void)hipHostFree(s->h_extcounts); (void)hipHostFree(s->h_stage);
+        (void)hipHostFree(s->h_knn); (void)hipHostFree(s->h_ctrl); (void)hipFree(s->d_ctrl);
+        (void)hipHostFree(s->h_stage);
         (void)hipHostFree(s->h_desc); (void)hipHostFree(s->h_angles);
         for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
         if (s->st) (void)hipStreamDestroy(s->st);
+        if (s->st_copy) (void)hipStreamDestroy(s->st_copy);
+        if (s->st_dma) (void)hipStreamDestroy(s->st_dma);
         delete s;
     }
     slots.clear();
@@ -463,7 +531,7 @@ void Rig::driver(Slot *sp)
             if (st == MCORB_OK) st = finish_match(s, j);
             break;
         case Job::MATCH:
-            st = enqueue_match(s, j);
+            st = enqueue_match(s, j, false);
             if (st == MCORB_OK) {
                 hipError_t e = hipStreamSynchronize(s.st);
                 if (e != hipSuccess) { set_error(hipGetErrorString(e)); st = MCORB_E_HIP; }
@@ -487,11 +555,16 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
     if (j.nimg < 1 || j.nimg > max_images) { set_error("extract: bad image count"); return MCORB_E_ARG; }
     s.h_overflow[0] = 0;
     HIPCHK(hipEventRecord(s.ev[0], s.st));
-    launch_pyramid(s.st, s.d_pyr, geom, d_taps, j.nimg);
+    launch_pyramid(s.st, s.d_pyr, geom, d_taps, resize_win, j.nimg);
     HIPCHK(hipEventRecord(s.ev[1], s.st));
-    launch_fast(s.st, s.d_pyr, geom, params.ini_th_fast, params.min_th_fast, s.d_cellkp, s.d_cellcnt, s.h_cand,
-                s.h_lvloff, s.h_overflow, j.nimg, s.ev[2]);
-    HIPCHK(hipEventRecord(s.ev[3], s.st));
+    launch_fast(s.st, s.d_pyr, geom, params.ini_th_fast, params.min_th_fast, s.d_cellkp, s.d_cellcnt, j.nimg);
+    HIPCHK(hipEventRecord(s.ev[2], s.st));
+    // compaction writes the candidates over PCIe into host-mapped memory: run it on the side stream so
+    // the blur (which does not depend on it) overlaps the transfer
+    HIPCHK(hipStreamWaitEvent(s.st_copy, s.ev[2], 0));
+    launch_compact(s.st_copy, s.d_cellkp, s.d_cellcnt, geom, s.d_sorted, s.h_cand, s.h_lvloff, s.h_bstart, s.h_overflow,
+                   j.nimg);
+    HIPCHK(hipEventRecord(s.ev[3], s.st_copy));
     launch_blur(s.st, s.d_pyr, s.d_blur, geom, j.nimg);
     HIPCHK(hipEventRecord(s.ev[4], s.st));
     HIPCHK(hipGetLastError());
@@ -509,33 +582,31 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     const auto t0 = std::chrono::steady_clock::now();
     const int L = geom.nlevels, nimg = j.nimg;
     std::atomic<int> bad{0};
-    // selection: one task per (level, image), large levels first
-    pool->parallel_for(L * nimg, [&](int task, int w) {
-        const int level = task / nimg, m = task - level * nimg;
+    // selection + assembly: one task per image (all its levels); the host side of a level is now
+    // ~10 us of tree logic on GPU-bucketed candidates, so finer tasks would only pay pool overhead
+    pool->parallel_for(nimg, [&](int m, int w) {
         const int *lo = s.h_lvloff + (size_t)m * (kMaxLevels + 1);
-        const int n = lo[level + 1] - lo[level];
-        std::vector<int> &out = s.sel_idx[(size_t)m * L + level];
-        out.resize((size_t)tab.quota[level] + 64);
-        const LevelGeom &G = geom.lv[level];
-        int r = 0;
-        if (n > 0)
-            r = select_octree(s.h_cand + (size_t)m * geom.candCap + lo[level], n, kMinBorder, G.maxBorderX, kMinBorder,
-                              G.maxBorderY, tab.quota[level], out.data(), *scratch[w]);
-        if (r < 0) { bad.store(1); r = 0; }
-        out.resize(r);
-    });
-    if (bad.load()) { set_error("selection failed: level too tall"); (void)hipStreamSynchronize(s.st); return MCORB_E_SIZE; }
-    // assembly (ORBextractor.cpp:1103-1170): final order, lapping partition, coordinate scaling
-    pool->parallel_for(nimg, [&](int m, int) {
         int total = 0;
-        for (int l = 0; l < L; l++) total += (int)s.sel_idx[(size_t)m * L + l].size();
+        for (int level = 0; level < L; level++) {
+            const int n = lo[level + 1] - lo[level];
+            std::vector<int> &out = s.sel_idx[(size_t)m * L + level];
+            out.resize((size_t)tab.quota[level] + 64);
+            int r = 0;
+            if (n > 0)
+                r = select_octree(s.h_cand + (size_t)m * geom.candCap + lo[level],
+                                  s.h_bstart + (size_t)m * geom.bucketTotal + geom.lv[level].bucket0, n, selp[level],
+                                  out.data(), *scratch[w]);
+            if (r < 0) { bad.store(1); r = 0; }
+            out.resize(r);
+            total += r;
+        }
+        // assembly (ORBextractor.cpp:1103-1170): final order, lapping partition, coordinate scaling
         if (total > geom.kcap) { bad.store(2); total = 0; }
         std::vector<mcorb_keypoint> &K = s.kps[m];
         K.assign(total, mcorb_keypoint{});
         uint32_t *sel = s.h_sel + (size_t)m * geom.kcap;
         int monoIndex = 0, stereoIndex = total - 1;
         if (total) {
-            const int *lo = s.h_lvloff + (size_t)m * (kMaxLevels + 1);
             for (int l = 0; l < L; l++) {
                 const uint32_t *cand = s.h_cand + (size_t)m * geom.candCap + lo[l];
                 const float scale = tab.scale[l];
@@ -561,27 +632,34 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
         s.mono[m] = monoIndex;
         s.h_nsel[m] = total;
     });
+    if (bad.load() == 1) { set_error("selection failed: level too tall"); (void)hipStreamSynchronize(s.st); return MCORB_E_SIZE; }
     if (bad.load()) { set_error("keypoint capacity exceeded"); (void)hipStreamSynchronize(s.st); return MCORB_E_CAP; }
     const auto t1 = std::chrono::steady_clock::now();
     s.timing[1] = std::chrono::duration<float, std::micro>(t1 - t0).count();
 
-    HIPCHK(hipEventRecord(s.ev[5], s.st));
-    launch_describe(s.st, s.d_pyr, s.d_blur, geom, s.h_sel, s.h_nsel, params.orientation, s.d_desc, s.d_angles, nimg);
-    HIPCHK(hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)nimg * geom.kcap * 32, hipMemcpyDeviceToHost, s.st));
-    if (params.orientation)
-        HIPCHK(hipMemcpyAsync(s.h_angles, s.d_angles, (size_t)nimg * geom.kcap * sizeof(float), hipMemcpyDeviceToHost, s.st));
-    HIPCHK(hipEventRecord(s.ev[6], s.st));
     s.nimg_done = nimg;
-    if (then_match) TRY(enqueue_match(s, j));
+    if (then_match) TRY(prepare_match(s, j));
+    // one H2D copy of the control block: counts, pair list, packed selected keypoints
+    HIPCHK(hipMemcpyAsync(s.d_ctrl, s.h_ctrl, s.ctrl_bytes, hipMemcpyHostToDevice, s.st));
+    HIPCHK(hipEventRecord(s.ev[5], s.st));
+    launch_describe(s.st, s.d_pyr, s.d_blur, geom, s.d_sel, s.d_nsel, params.orientation, s.d_desc, s.d_angles, nimg);
+    HIPCHK(hipEventRecord(s.ev[6], s.st));
+    // descriptors go back to the host on the side stream (DMA) while the matcher already runs
+    HIPCHK(hipStreamWaitEvent(s.st_dma, s.ev[6], 0));
+    HIPCHK(hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)nimg * geom.kcap * 32, hipMemcpyDeviceToHost, s.st_dma));
+    if (params.orientation)
+        HIPCHK(hipMemcpyAsync(s.h_angles, s.d_angles, (size_t)nimg * geom.kcap * sizeof(float), hipMemcpyDeviceToHost, s.st_dma));
+    if (then_match) TRY(enqueue_match(s, j, true));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(s.st));
+    HIPCHK(hipStreamSynchronize(s.st_dma));
     if (params.orientation)
         for (int m = 0; m < nimg; m++)
             for (size_t k = 0; k < s.kps[m].size(); k++) s.kps[m][k].angle = s.h_angles[(size_t)m * geom.kcap + k];
     s.nimg_done = nimg;
     float a = 0, b = 0, c = 0, t = 0;
-    (void)hipEventElapsedTime(&a, s.ev[0], s.ev[3]);
-    (void)hipEventElapsedTime(&b, s.ev[3], s.ev[4]);
+    (void)hipEventElapsedTime(&a, s.ev[0], s.ev[2]);
+    (void)hipEventElapsedTime(&b, s.ev[2], s.ev[4]);
     (void)hipEventElapsedTime(&c, s.ev[5], s.ev[6]);
     s.timing[0] = a * 1000.f;
     s.timing[2] = (b + c) * 1000.f;
@@ -591,7 +669,8 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     return MCORB_OK;
 }
 
-int Rig::enqueue_match(Slot &s, const Job &j)
+// fills the host side of the control block for a match: per-(frame,cam) sets/counts and the pair list
+int Rig::prepare_match(Slot &s, const Job &j)
 {
     const bool ext = j.ext_desc != nullptr;
     if (j.nframes < 1 || j.nframes > max_frames || (!ext && j.nframes * ncams > s.nimg_done)) {
@@ -615,18 +694,27 @@ int Rig::enqueue_match(Slot &s, const Job &j)
         for (int i = 0; i < j.nframes * C; i++) { s.match_sets[i] = i; s.match_counts[i] = s.h_nsel[i]; }
     }
     s.nframes_done = j.nframes;
-    s.npairs_done = 0;
-    if (npp == 0) return MCORB_OK;
     int p = 0;
     for (int f = 0; f < j.nframes; f++)
         for (int a = 0; a < C - 1; a++)
             for (int b = a + 1; b < C; b++) s.h_pairs[p++] = int2{s.match_sets[f * C + a], s.match_sets[f * C + b]};
+    s.npairs_done = p;
+    return MCORB_OK;
+}
+
+int Rig::enqueue_match(Slot &s, const Job &j, bool ctrl_on_device)
+{
+    if (!ctrl_on_device) {
+        TRY(prepare_match(s, j));
+        HIPCHK(hipMemcpyAsync(s.d_ctrl, s.h_ctrl, s.ctrl_pairs_end, hipMemcpyHostToDevice, s.st));
+    }
+    if (s.npairs_done == 0) return MCORB_OK;
+    const bool ext = j.ext_desc != nullptr;
     HIPCHK(hipEventRecord(s.ev[7], s.st));
-    launch_knn2(s.st, ext ? (const uint8_t *)j.ext_desc : s.d_desc, ext ? s.h_extcounts : s.h_nsel, s.h_pairs, p,
-                geom.kcap, s.d_part, j.dist_thresh, j.ratio, s.h_knn, s.ev[8]);
+    launch_knn2(s.st, ext ? (const uint8_t *)j.ext_desc : s.d_desc, ext ? s.d_extcounts : s.d_nsel, s.d_pairs,
+                s.npairs_done, geom.kcap, s.d_part, j.dist_thresh, j.ratio, s.h_knn, s.ev[8]);
     HIPCHK(hipEventRecord(s.ev[9], s.st));
     HIPCHK(hipGetLastError());
-    s.npairs_done = p;
     return MCORB_OK;
 }
 
@@ -651,7 +739,7 @@ int Rig::finish_match(Slot &s, const Job &j)
                 const KnnRow *rows = s.h_knn + (size_t)pi * geom.kcap;
                 for (int q = 0; q < nq; q++) {
                     const KnnRow &r = rows[q];
-                    if (r.idx1 >= 0 && ((r.d1 >> 30) & 1)) { i1.push_back((uint32_t)q); i2.push_back((uint32_t)r.idx0); }
+                    if (knn_accept(r)) { i1.push_back((uint32_t)q); i2.push_back((uint32_t)knn_idx0(r)); }
                 }
                 for (size_t k = 0; k < i1.size(); k++) {
                     const int fa = (int)i1[k], fb = (int)i2[k];

@@ -51,6 +51,7 @@ private:
         std::atomic<int> next{0};
         int n = 0;
         std::atomic<int> done{0};
+        std::atomic<int> refs{0};
         std::mutex m;
         std::condition_variable cv;
     };
@@ -59,6 +60,7 @@ private:
     std::mutex m_;
     std::condition_variable cv_;
     std::vector<Batch *> queue_;
+    std::atomic<int> pending_{0};   // batches in queue_ (lets idle workers spin without the lock)
     bool stop_ = false;
 };
 
@@ -79,23 +81,29 @@ class Rig;
 struct Slot {
     Rig *rig = nullptr;
     int index = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr, st_copy = nullptr, st_dma = nullptr;   // compute; PCIe-bound compaction kernel; D2H copies only
     hipEvent_t ev[12] = {};  // 0 start, 1 pyramid done, 2 FAST done, 3 compact done, 4 blur done, 5/6 describe(+D2H), 7 knn2 start, 8 knn2 done, 9 finalize done
     // device
     uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_desc = nullptr;
-    uint32_t *d_cellkp = nullptr;
+    uint32_t *d_cellkp = nullptr, *d_sorted = nullptr;
     int *d_cellcnt = nullptr;
     float *d_angles = nullptr, *d_f32 = nullptr;
     uint2 *d_part = nullptr;
     size_t f32_bytes = 0;
     // host, device-mapped (kernels write/read these directly over PCIe)
     uint32_t *h_cand = nullptr;
-    int *h_lvloff = nullptr, *h_overflow = nullptr;
-    uint32_t *h_sel = nullptr;
-    int *h_nsel = nullptr;
+    int *h_lvloff = nullptr, *h_overflow = nullptr, *h_bstart = nullptr;
     KnnRow *h_knn = nullptr;
+    // control block: one pinned host buffer + one device mirror, copied with a single
+    // hipMemcpyAsync: [extcounts 4096 ints][nsel][pairs][sel]
+    uint8_t *h_ctrl = nullptr, *d_ctrl = nullptr;
+    size_t ctrl_pairs_end = 0, ctrl_bytes = 0;
+    int *h_extcounts = nullptr, *h_nsel = nullptr;
     int2 *h_pairs = nullptr;
-    int *h_extcounts = nullptr;
+    uint32_t *h_sel = nullptr;
+    int *d_extcounts = nullptr, *d_nsel = nullptr;
+    int2 *d_pairs = nullptr;
+    uint32_t *d_sel = nullptr;
     // host, pinned
     uint8_t *h_stage = nullptr, *h_desc = nullptr;
     float *h_angles = nullptr;
@@ -138,6 +146,8 @@ public:
     int ncams = 0, W = 0, H = 0, max_frames = 0, max_images = 0, npp = 0 /* pairs per frame */;
     int device = 0;
     ResizeTap *d_taps = nullptr;
+    SelectParams selp[kMaxLevels];         // per-level DistributeOctTree constants + bucketing depth
+    int resize_win[2 * kMaxLevels] = {};   // per level: LDS window pitch, rows (see launch_pyramid)
     std::vector<Slot *> slots;
     WorkerPool *pool = nullptr;
     std::vector<SelectScratch *> scratch;   // one per worker
@@ -146,7 +156,8 @@ private:
     void driver(Slot *s);
     int run_extract_phaseA(Slot &s, const Job &j);
     int run_select_and_describe(Slot &s, const Job &j, bool then_match);
-    int enqueue_match(Slot &s, const Job &j);
+    int prepare_match(Slot &s, const Job &j);
+    int enqueue_match(Slot &s, const Job &j, bool ctrl_on_device);
     int finish_match(Slot &s, const Job &j);
 };
 

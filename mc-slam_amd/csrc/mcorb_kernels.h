@@ -7,16 +7,25 @@ namespace mcorb {
 
 constexpr int kKnnChunk = 256;   // train descriptors staged in LDS per workgroup (8 KiB)
 
-// one row of the knnMatch(k=2) table; bit 30 of d1 carries BruteForceMatch's accept flag
-struct KnnRow { int32_t idx0, idx1, d0, d1; };
+// one row of the knnMatch(k=2) table, 8 bytes so the PCIe write-back stays small:
+// idx = trainIdx0 | trainIdx1 << 16 (0xffff = absent), d = dist0 | dist1 << 9 | accept << 18
+// (accept = BruteForceMatch's ratio + threshold test)
+struct KnnRow { uint32_t idx, d; };
+__host__ __device__ inline int knn_idx0(const KnnRow &r) { return (r.idx & 0xffffu) == 0xffffu ? -1 : (int)(r.idx & 0xffffu); }
+__host__ __device__ inline int knn_idx1(const KnnRow &r) { return (r.idx >> 16) == 0xffffu ? -1 : (int)(r.idx >> 16); }
+__host__ __device__ inline int knn_d0(const KnnRow &r) { return knn_idx0(r) < 0 ? -1 : (int)(r.d & 0x1ffu); }
+__host__ __device__ inline int knn_d1(const KnnRow &r) { return knn_idx1(r) < 0 ? -1 : (int)((r.d >> 9) & 0x1ffu); }
+__host__ __device__ inline bool knn_accept(const KnnRow &r) { return (r.d >> 18) & 1u; }
 
 hipError_t upload_umax(const int umax[16]);
 void launch_stage_f32(hipStream_t st, const float *src, int w, int h, int pitch_f, int channels, size_t img_stride_f,
                       uint8_t *pyr, const Geom &g, int nimg);
-void launch_pyramid(hipStream_t st, uint8_t *pyr, const Geom &g, const ResizeTap *tabs, int nimg);
-// ev_mid (optional) is recorded between the two kernels so each can be timed on its own
+// win[2*l], win[2*l+1]: LDS source-window pitch (bytes, multiple of 4) and rows of level l's resize workgroups
+void launch_pyramid(hipStream_t st, uint8_t *pyr, const Geom &g, const ResizeTap *tabs, const int *win, int nimg);
 void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, uint32_t *cell_kp,
-                 int *cell_cnt, uint32_t *cand, int *lvl_off, int *overflow, int nimg, hipEvent_t ev_mid);
+                 int *cell_cnt, int nimg);
+void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt, const Geom &g, uint32_t *sorted_dev,
+                    uint32_t *cand, int *lvl_off, int *bstart, int *overflow, int nimg);
 void launch_blur(hipStream_t st, const uint8_t *pyr, uint8_t *blur, const Geom &g, int nimg);
 void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, const Geom &g, const uint32_t *sel,
                      const int *nsel, int orientation, uint8_t *desc, float *angles, int nimg);

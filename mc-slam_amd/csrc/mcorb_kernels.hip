@@ -60,29 +60,53 @@ __global__ __launch_bounds__(256) void k_stage_f32(const float *__restrict__ src
 // ---------------------------------------------------------------------------
 // Pyramid: level L from level L-1, cv::resize INTER_LINEAR 8UC1 fixed point
 // (ComputePyramid, ORBextractor.cpp:1173-1198; coefficients: host tables).
-// Thread = 4 consecutive output pixels of one row -> one dword store.
+// Workgroup = 256 x 4 output pixels.  The source window it needs (a few rows,
+// ~1.2 x 256 columns) is staged in LDS with aligned dword loads; each thread
+// then produces 4 consecutive output pixels of one row -> one dword store.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom g, int level,
-                                                const ResizeTap *__restrict__ tabs)
+                                                const ResizeTap *__restrict__ tabs, int srcPitch, int srcRows)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t win[];   // srcRows x srcPitch bytes
     const LevelGeom &D = g.lv[level];
     const LevelGeom &S = g.lv[level - 1];
     const int img = blockIdx.z;
     uint8_t *base = pyr + (size_t)img * g.imgBytes;
-    const int dx4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int tid = threadIdx.x;
+    const int bx0 = blockIdx.x * 256, by0 = blockIdx.y * 4;
+    const int bx1 = min(bx0 + 255, D.w - 1), by1 = min(by0 + 3, D.h - 1);
+    // source window of this workgroup (tables are monotone)
+    const int sx0 = tabs[D.xtab + bx0].s0 & ~3, sx1 = tabs[D.xtab + bx1].s1;
+    const int sy0 = tabs[D.ytab + by0].s0, sy1 = tabs[D.ytab + by1].s1;
+    const int nd = ((sx1 - sx0) >> 2) + 1, nr = sy1 - sy0 + 1;   // nd*4 <= srcPitch, nr <= srcRows by construction
+    {
+        const uint8_t *sp = base + S.off + (size_t)sy0 * S.pitch + sx0;
+        uint32_t *w32 = reinterpret_cast<uint32_t *>(win);
+        const int pd = srcPitch >> 2;
+        for (int i = tid; i < nr * pd; i += 256) {
+            const int r = i / pd, d = i - r * pd;
+            if (d < nd) w32[i] = *reinterpret_cast<const uint32_t *>(sp + (size_t)r * S.pitch + 4 * d);
+        }
+    }
+    __syncthreads();
+    const int dx4 = bx0 + (tid & 63) * 4;
+    const int dy = by0 + (tid >> 6);
     if (dy >= D.h || dx4 >= D.w) return;
     const ResizeTap ty = tabs[D.ytab + dy];
-    const uint8_t *S0 = base + S.off + (size_t)ty.s0 * S.pitch;
-    const uint8_t *S1 = base + S.off + (size_t)ty.s1 * S.pitch;
+    const uint8_t *S0 = win + (ty.s0 - sy0) * srcPitch - sx0;
+    const uint8_t *S1 = win + (ty.s1 - sy0) * srcPitch - sx0;
     const int b0 = ty.c0, b1 = ty.c1;
+    const uint4 t01 = *reinterpret_cast<const uint4 *>(tabs + D.xtab + dx4);       // 4 taps, 8 bytes each
+    const uint4 t23 = *reinterpret_cast<const uint4 *>(tabs + D.xtab + dx4 + 2);
+    const uint32_t tw[8] = {t01.x, t01.y, t01.z, t01.w, t23.x, t23.y, t23.z, t23.w};
     uint32_t out = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const ResizeTap tx = tabs[D.xtab + dx4 + k];   // table is padded to a multiple of 4 entries
-        const int a0 = tx.c0, a1 = tx.c1;
-        const int R0 = S0[tx.s0] * a0 + S0[tx.s1] * a1;
-        const int R1 = S1[tx.s0] * a0 + S1[tx.s1] * a1;
+        const int s0 = tw[2 * k] & 0xffff, s1 = tw[2 * k] >> 16;
+        const int a0 = (int)(short)(tw[2 * k + 1] & 0xffff), a1 = (int)(short)(tw[2 * k + 1] >> 16);
+        const bool ok = dx4 + k < D.w;   // padded taps point at column 0 of the image, which may be outside the window
+        const int R0 = ok ? S0[s0] * a0 + S0[s1] * a1 : 0;
+        const int R1 = ok ? S1[s0] * a0 + S1[s1] * a1 : 0;
         const int v = (((b0 * (R0 >> 4)) >> 16) + ((b1 * (R1 >> 4)) >> 16) + 2) >> 2;
         out |= (uint32_t)(v & 0xff) << (8 * k);
     }
@@ -103,18 +127,26 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
 // NMS pass over the same A map.  The dark and bright arcs are evaluated
 // together in packed 16-bit lanes (v_pk_min_i16 / v_pk_max_i16).
 // ---------------------------------------------------------------------------
-constexpr int kFastMaxIts = 24;   // ceil(70*70/256) = 20
-
-__device__ __forceinline__ int fast_arc_max(const uint8_t *c)
+// One WAVE per cell (workgroup = 64 threads): every phase is wave-synchronous, so there is no
+// s_barrier anywhere and up to 32 cells are in flight per CU to hide LDS/HBM latency.
+//   pass 1  necessary condition at the lower threshold on every interior pixel (5 LDS bytes):
+//           any 9-arc of the 16-ring holds two neighbouring compass points (k, k+4), so a corner
+//           needs such a pair both darker or both brighter than the centre by more than t;
+//   pass 2  survivors are compacted through a 128-entry LDS ring (ballot + popcount) and the full
+//           arc score is evaluated 64 at a time with all lanes busy;
+//   pass 3  3x3 NMS on the score map, keypoints emitted straight to the cell's slot in raster
+//           order (running wave-uniform offset += popcount(ballot)); if the cell produced nothing
+//           at iniTh the pass is repeated at minTh (the reference's second cv::FAST call).
+__device__ __forceinline__ int fast_arc_max(const uint8_t *c, int TP)
 {
     // ring offsets (dx,dy), k = 0..15 (cv::FAST makeOffsets, patternSize 16)
-    constexpr int TP = kTilePitch;
     const int v = c[0];
+    const int T2 = 2 * TP, T3 = 3 * TP;
     int r[16];
-    r[0] = c[3 * TP];        r[1] = c[3 * TP + 1];   r[2] = c[2 * TP + 2];   r[3] = c[TP + 3];
-    r[4] = c[3];             r[5] = c[-TP + 3];      r[6] = c[-2 * TP + 2];  r[7] = c[-3 * TP + 1];
-    r[8] = c[-3 * TP];       r[9] = c[-3 * TP - 1];  r[10] = c[-2 * TP - 2]; r[11] = c[-TP - 3];
-    r[12] = c[-3];           r[13] = c[TP - 3];      r[14] = c[2 * TP - 2];  r[15] = c[3 * TP - 1];
+    r[0] = c[T3];        r[1] = c[T3 + 1];   r[2] = c[T2 + 2];   r[3] = c[TP + 3];
+    r[4] = c[3];         r[5] = c[-TP + 3];  r[6] = c[-T2 + 2];  r[7] = c[-T3 + 1];
+    r[8] = c[-T3];       r[9] = c[-T3 - 1];  r[10] = c[-T2 - 2]; r[11] = c[-TP - 3];
+    r[12] = c[-3];       r[13] = c[TP - 3];  r[14] = c[T2 - 2];  r[15] = c[T3 - 1];
     s16x2 p[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
@@ -135,16 +167,39 @@ __device__ __forceinline__ int fast_arc_max(const uint8_t *c)
     return a < 0 ? 0 : a;   // <= 255
 }
 
-__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom g, int iniTh, int minTh,
-                                                    uint32_t *__restrict__ cell_kp, int *__restrict__ cell_cnt)
+// 8-point necessary condition (ring positions 0,2,..,14): a 9-arc covers at least 4 cyclically
+// consecutive even positions, so a corner at threshold t needs 4 such points all darker or all
+// brighter than the centre by more than t.  Returns max over those quadruples of min(|d|) (signed).
+__device__ __forceinline__ int fast_even8_max(const uint8_t *c, int TP)
 {
-    constexpr int TP = kTilePitch;
-    __shared__ __attribute__((aligned(16))) uint8_t tile[kMaxRoi * TP];
-    __shared__ __attribute__((aligned(16))) uint8_t sc[kMaxRoi * TP];
-    __shared__ int wcnt[kFastMaxIts * 4 + 4];
-    __shared__ int s_total;
+    const int v = c[0];
+    const int T2 = 2 * TP, T3 = 3 * TP;
+    const int r[8] = {c[T3], c[T2 + 2], c[3], c[-T2 + 2], c[-T3], c[-T2 - 2], c[-3], c[T2 - 2]};
+    s16x2 e[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int d = v - r[k];
+        e[k] = s16x2{(short)d, (short)(-d)};
+    }
+    s16x2 m2[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) m2[k] = __builtin_elementwise_min(e[k], e[(k + 1) & 7]);
+    s16x2 best = __builtin_elementwise_min(m2[0], m2[2]);
+#pragma unroll
+    for (int k = 1; k < 8; k++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m2[k], m2[(k + 2) & 7]));
+    return best.x > best.y ? best.x : best.y;
+}
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom g, int iniTh, int minTh,
+                                                   int tileBytes, uint32_t *__restrict__ cell_kp,
+                                                   int *__restrict__ cell_cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // tile | score map | work list
+    uint8_t *tile = lds;
+    uint8_t *sc = lds + tileBytes;
+    uint16_t *work = reinterpret_cast<uint16_t *>(lds + 2 * tileBytes);
+
+    const int lane = threadIdx.x;
     const int cell = blockIdx.x, img = blockIdx.y;
     int level = 0;
 #pragma unroll 1
@@ -166,7 +221,7 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const int cols = maxX - iniX, rows = maxY - iniY;
     const int wi = cols - 6, hi = rows - 6;   // FAST evaluates ROI columns 3..cols-4, rows 3..rows-4
     if (skip || wi <= 0 || hi <= 0) {
-        if (tid == 0) *out_cnt = 0;
+        if (lane == 0) *out_cnt = 0;
         return;
     }
 
@@ -174,149 +229,310 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t *__restrict__ 
     const uint8_t *plane = pyr + (size_t)img * g.imgBytes + L.off;
     const int ph = iniX & 3;
     const int nd = (ph + cols + 3) >> 2;   // dwords per row, <= 20
+    const int TP = nd * 4;                 // LDS pitch of this cell
     {
         const uint8_t *src0 = plane + (size_t)iniY * L.pitch + (iniX - ph);
         uint32_t *t32 = reinterpret_cast<uint32_t *>(tile);
         uint32_t *s32 = reinterpret_cast<uint32_t *>(sc);
-        for (int i = tid; i < rows * (TP / 4); i += 256) {
-            const int y = i / (TP / 4), d = i - y * (TP / 4);
+        const float rcp_nd = 1.0f / (float)nd;
+        for (int i = lane; i < rows * nd; i += 64) {
+            const int y = (int)(((float)i + 0.5f) * rcp_nd), d = i - y * nd;
             s32[i] = 0;
-            if (d < nd) t32[i] = *reinterpret_cast<const uint32_t *>(src0 + (size_t)y * L.pitch + 4 * d);
+            t32[i] = *reinterpret_cast<const uint32_t *>(src0 + (size_t)y * L.pitch + 4 * d);
+        }
+    }
+    __syncthreads();   // single-wave workgroup: lowers to a wait, not an s_barrier
+
+    const float rcp_tp = 1.0f / (float)TP;
+    const int tlo = iniTh < minTh ? iniTh : minTh;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    // ---- pass 1: 4-point test, 4 horizontally adjacent pixels per lane: five aligned LDS dwords
+    //      (centre, left, right, 3 rows up, 3 rows down) feed packed 16-bit min/max; survivors are
+    //      appended in raster order (lane-major, then byte position) ----
+    int nA = 0;
+    {
+        const uint32_t *t32 = reinterpret_cast<const uint32_t *>(tile);
+        const int g0 = (ph + 3) >> 2, g1 = (ph + 2 + wi) >> 2, ng = g1 - g0 + 1;
+        const int nw = hi * ng;
+        const float rcp_ng = 1.0f / (float)ng;
+        const int cmin = ph + 3, cmax = ph + 3 + wi;   // valid tile columns [cmin, cmax)
+        const s16x2 zero = {0, 0};
+        for (int w0 = 0; w0 < nw; w0 += 64) {
+            const int w = w0 + lane;
+            bool c0 = false, c1 = false, c2 = false, c3 = false;
+            int pos = 0;
+            if (w < nw) {
+                const int r = (int)(((float)w + 0.5f) * rcp_ng), gq = g0 + (w - r * ng);
+                const int di = (r + 3) * nd + gq;
+                const uint32_t C = t32[di], Cl = t32[di - 1], Cr = t32[di + 1], U = t32[di - 3 * nd], Dn = t32[di + 3 * nd];
+                const uint32_t Lf = __builtin_amdgcn_alignbyte(C, Cl, 1);   // columns 4g-3 .. 4g
+                const uint32_t Rt = __builtin_amdgcn_alignbyte(Cr, C, 3);   // columns 4g+3 .. 4g+6
+                pos = (r + 3) * TP + 4 * gq;
+                int m[4];
+#pragma unroll
+                for (int hgh = 0; hgh < 2; hgh++) {
+                    const uint32_t sel = hgh ? 0x0c030c02u : 0x0c010c00u;
+#define UNP(X) __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, X, sel))
+                    const s16x2 V = UNP(C);
+                    const s16x2 d0 = V - UNP(Dn), d4 = V - UNP(Rt), d8 = V - UNP(U), d12 = V - UNP(Lf);
+#undef UNP
+                    const s16x2 lo = __builtin_elementwise_max(
+                        __builtin_elementwise_max(__builtin_elementwise_min(d0, d4), __builtin_elementwise_min(d4, d8)),
+                        __builtin_elementwise_max(__builtin_elementwise_min(d8, d12), __builtin_elementwise_min(d12, d0)));
+                    const s16x2 hi2 = __builtin_elementwise_min(
+                        __builtin_elementwise_min(__builtin_elementwise_max(d0, d4), __builtin_elementwise_max(d4, d8)),
+                        __builtin_elementwise_min(__builtin_elementwise_max(d8, d12), __builtin_elementwise_max(d12, d0)));
+                    const s16x2 mm = __builtin_elementwise_max(lo, zero - hi2);
+                    m[2 * hgh] = mm.x;
+                    m[2 * hgh + 1] = mm.y;
+                }
+                const int col = 4 * gq;
+                c0 = m[0] > tlo && col >= cmin && col < cmax;
+                c1 = m[1] > tlo && col + 1 >= cmin && col + 1 < cmax;
+                c2 = m[2] > tlo && col + 2 >= cmin && col + 2 < cmax;
+                c3 = m[3] > tlo && col + 3 >= cmin && col + 3 < cmax;
+            }
+            const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1), b2 = __ballot(c2), b3 = __ballot(c3);
+            int o = nA + __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
+            if (c0) work[o++] = (uint16_t)pos;
+            if (c1) work[o++] = (uint16_t)(pos + 1);
+            if (c2) work[o++] = (uint16_t)(pos + 2);
+            if (c3) work[o++] = (uint16_t)(pos + 3);
+            nA += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
         }
     }
     __syncthreads();
 
-    // ---- arc score A for every interior pixel ----
-    const int ni = wi * hi;
-    const int nits = (ni + 255) >> 8;
-    for (int it = 0; it < nits; it++) {
-        const int p = it * 256 + tid;
-        if (p < ni) {
-            const int y = p / wi, x = p - y * wi;
-            const int a = fast_arc_max(tile + (y + 3) * TP + ph + x + 3);
-            sc[(y + 3) * TP + x + 3] = (uint8_t)a;
+    // ---- pass 2a: 8-point test on the survivors, compacted in place (writes never pass the reads) ----
+    int nB = 0;
+    for (int i0 = 0; i0 < nA; i0 += 64) {
+        const int i = i0 + lane;
+        int pos = 0;
+        bool cand = false;
+        if (i < nA) {
+            pos = work[i];
+            cand = fast_even8_max(tile + pos, TP) > tlo;
         }
+        const unsigned long long b = __ballot(cand);
+        __syncthreads();
+        if (cand) work[nB + __popcll(b & lt)] = (uint16_t)pos;
+        nB += __popcll(b);
     }
     __syncthreads();
 
-    // ---- NMS at iniTh, then (only if the cell came out empty) at minTh ----
-    uint32_t keepmask = 0;
+    // ---- pass 2b: full arc score for what is left ----
+    for (int i = lane; i < nB; i += 64) {
+        const int pos = work[i];
+        sc[pos] = (uint8_t)fast_arc_max(tile + pos, TP);
+    }
+    __syncthreads();
+
+    // ---- pass 3: NMS over the work list at iniTh, then (only if the cell came out empty) at minTh;
+    //      the list is in raster order, so keypoints are emitted in cv::FAST's order ----
+    uint32_t *dst = cell_kp + ((size_t)img * g.cells + cell) * g.cellCap;
+    int total = 0;
     int T = iniTh;
     for (int attempt = 0; attempt < 2; attempt++) {
-        keepmask = 0;
-        int mine = 0;
-        for (int it = 0; it < nits; it++) {
-            const int p = it * 256 + tid;
+        for (int i0 = 0; i0 < nB; i0 += 64) {
+            const int i = i0 + lane;
             bool keep = false;
-            if (p < ni) {
-                const int y = p / wi, x = p - y * wi;
-                const uint8_t *s = sc + (y + 3) * TP + x + 3;
-                const int a = s[0];
+            int pos = 0, a = 0;
+            if (i < nB) {
+                pos = work[i];
+                const uint8_t *s = sc + pos;
+                a = s[0];
                 if (a > T) {
                     const int e = a - 1;   // cornerScore
 #define EFF(q) ((int)(q) > T ? (int)(q)-1 : 0)
-                    keep = e > EFF(s[1]) && e > EFF(s[-1]) && e > EFF(s[-TP - 1]) && e > EFF(s[-TP]) &&
-                           e > EFF(s[-TP + 1]) && e > EFF(s[TP - 1]) && e > EFF(s[TP]) && e > EFF(s[TP + 1]);
+                    const int n0 = max(max(EFF(s[1]), EFF(s[-1])), max(EFF(s[-TP - 1]), EFF(s[-TP])));
+                    const int n1 = max(max(EFF(s[-TP + 1]), EFF(s[TP - 1])), max(EFF(s[TP]), EFF(s[TP + 1])));
 #undef EFF
+                    keep = e > max(n0, n1);
                 }
             }
             const unsigned long long b = __ballot(keep);
-            if (lane == 0) wcnt[it * 4 + wave] = __popcll(b);
-            if (keep) { keepmask |= 1u << it; mine++; }
-        }
-        const int total = __syncthreads_count(mine > 0) ? 1 : 0;
-        if (total || T == minTh || attempt == 1) break;
-        T = minTh;
-        __syncthreads();
-    }
-
-    // ---- exclusive scan of the (iteration, wave) counts by wave 0 ----
-    const int nc = nits * 4;
-    if (wave == 0) {
-        int carry = 0;
-        for (int base = 0; base < nc; base += 64) {
-            const int i = base + lane;
-            const int v = i < nc ? wcnt[i] : 0;
-            int s = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(s, o);
-                if (lane >= o) s += t;
+            if (keep) {
+                const int o = total + __popcll(b & lt);
+                const int yy = (int)(((float)pos + 0.5f) * rcp_tp), xx = pos - yy * TP - ph;   // ROI coordinates
+                // keypoint coordinates relative to minBorder: FAST's ROI coordinate + cell origin (:864-865)
+                if (o < g.cellCap) dst[o] = pack_cand(xx + cj * L.wCell, yy + ci * L.hCell, a - 1);
             }
-            if (i < nc) wcnt[i] = carry + s - v;
-            carry += __shfl(s, 63);
+            total += __popcll(b);
         }
-        if (lane == 0) s_total = carry;
+        if (total || T == minTh) break;
+        T = minTh;
     }
-    __syncthreads();
-    const int total = s_total;
-    if (tid == 0) *out_cnt = total;
-    if (total == 0) return;
-
-    // ---- ordered emission: raster order inside the cell == cv::FAST's output order ----
-    uint32_t *dst = cell_kp + ((size_t)img * g.cells + cell) * g.cellCap;
-    for (int it = 0; it < nits; it++) {
-        const bool keep = (keepmask >> it) & 1u;
-        const unsigned long long b = __ballot(keep);
-        if (keep) {
-            const int pos = wcnt[it * 4 + wave] + __popcll(b & ((1ull << lane) - 1ull));
-            const int p = it * 256 + tid;
-            const int y = p / wi, x = p - y * wi;
-            const int a = sc[(y + 3) * TP + x + 3];
-            // keypoint coordinates relative to minBorder: FAST's ROI coordinate + cell origin (:864-865)
-            if (pos < g.cellCap) dst[pos] = pack_cand(x + 3 + cj * L.wCell, y + 3 + ci * L.hCell, a - 1);
-        }
-    }
+    if (lane == 0) *out_cnt = total;
 }
 
 // ---------------------------------------------------------------------------
 // Candidate compaction: per-cell lists -> one contiguous list per image in
 // (level, cell row, cell col, raster) order == vToDistributeKeys order of every
-// level back to back.  Written straight into host-mapped memory; lvl_off gets
-// nlevels+1 offsets per image.
+// level back to back.  One workgroup per (level, image): scan of the level's
+// cell counts in LDS, then a fully coalesced copy (binary search of the owning
+// cell per output element).  Written straight into host-mapped memory; lvl_off
+// gets nlevels+1 offsets per image.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_compact(const uint32_t *__restrict__ cell_kp, const int *__restrict__ cell_cnt,
-                                                 Geom g, uint32_t *__restrict__ cand, int *__restrict__ lvl_off,
-                                                 int *__restrict__ overflow)
+__device__ __forceinline__ int block_exclusive_scan_1024(int v, int *wsum, int *total)
 {
-    __shared__ int red[4];
-    const int tid = threadIdx.x;
-    const int cell = blockIdx.x, img = blockIdx.y;
-    const int *cnt = cell_cnt + (size_t)img * g.cells;
-    int s = 0;
-    for (int c = tid; c < cell; c += 256) s += cnt[c];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int s = v;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-    if ((tid & 63) == 0) red[tid >> 6] = s;
-    __syncthreads();
-    const int offset = red[0] + red[1] + red[2] + red[3];
-    int n = cnt[cell];
-    if (n > g.cellCap) n = g.cellCap;
-    if (tid == 0) {
-        for (int l = 0; l < g.nlevels; l++)
-            if (cell == g.lv[l].cell0) lvl_off[(size_t)img * (kMaxLevels + 1) + l] = offset;
-        if (cell == g.cells - 1) lvl_off[(size_t)img * (kMaxLevels + 1) + g.nlevels] = offset + n;
-        if (offset + n > g.candCap || cnt[cell] > g.cellCap) atomicOr(overflow, 1);
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(s, o);
+        if (lane >= o) s += t;
     }
-    const uint32_t *src = cell_kp + ((size_t)img * g.cells + cell) * g.cellCap;
-    uint32_t *dst = cand + (size_t)img * g.candCap;
-    for (int k = tid; k < n; k += 256)
-        if (offset + k < g.candCap) dst[offset + k] = src[k];
+    if (lane == 63) wsum[wave] = s;
+    __syncthreads();
+    if (wave == 0) {
+        const int w = lane < 16 ? wsum[lane] : 0;
+        int t = w;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+            const int u = __shfl_up(t, o);
+            if (lane >= o) t += u;
+        }
+        if (lane < 16) wsum[lane] = t - w;
+        if (lane == 15) *total = t;
+    }
+    __syncthreads();
+    return wsum[wave] + s - v;
+}
+
+// Besides compacting, the kernel sorts each level's candidates by quad-tree path code
+// (path_code(), depth g.lv[level].depth) with an LDS counting sort and hands the host the bucket
+// start offsets: the host-side DistributeOctTree logic then gets every node's key count in O(1)
+// and never has to partition the candidate list itself for the first `depth` splits.
+// Order inside a bucket is arbitrary; the selection only depends on the key SETS (the
+// "first maximum wins" tie is resolved from the coordinates, which encode the original order).
+__global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ cell_kp, const int *__restrict__ cell_cnt,
+                                                  Geom g, uint32_t *__restrict__ sorted_dev, uint32_t *__restrict__ cand,
+                                                  int *__restrict__ lvl_off, int *__restrict__ bstart,
+                                                  int *__restrict__ overflow, int exclCap)
+{
+    extern __shared__ int sh[];     // excl[exclCap] | hist[nBuckets + 1]
+    int *excl = sh;                 // exclusive offsets of this level's cells (+1 entry for the total)
+    int *hist = sh + exclCap;
+    __shared__ int wsum[16];
+    __shared__ int s_tot, s_base;
+    const int tid = threadIdx.x;
+    const int level = blockIdx.x, img = blockIdx.y;
+    const LevelGeom &L = g.lv[level];
+    const int nc = L.nCols * L.nRows;
+    const int *cnt = cell_cnt + (size_t)img * g.cells;
+    const int cap = g.cellCap;
+    const int B = L.nBuckets;
+
+    // candidates of all previous levels of this image
+    int s = 0, over = 0;
+    for (int c = tid; c < L.cell0; c += 1024) { const int v = cnt[c]; s += v < cap ? v : cap; }
+    (void)block_exclusive_scan_1024(s, wsum, &s_base);
+    const int base = s_base;
+    for (int b = tid; b <= B; b += 1024) hist[b] = 0;
+    __syncthreads();
+
+    // exclusive scan over this level's cells: each thread owns a contiguous run of cells
+    const int per = (nc + 1023) >> 10;
+    const int c0 = tid * per;
+    int mysum = 0;
+    for (int k = 0; k < per; k++) {
+        const int c = c0 + k;
+        if (c < nc) { int v = cnt[L.cell0 + c]; if (v > cap) { v = cap; over = 1; } mysum += v; }
+    }
+    int run = block_exclusive_scan_1024(mysum, wsum, &s_tot);
+    for (int k = 0; k < per; k++) {
+        const int c = c0 + k;
+        if (c < nc) { excl[c] = run; const int v = cnt[L.cell0 + c]; run += v < cap ? v : cap; }
+    }
+    int T = s_tot;
+    if (tid == 0) {
+        excl[nc] = T;
+        lvl_off[(size_t)img * (kMaxLevels + 1) + level] = base;
+        if (level == g.nlevels - 1) lvl_off[(size_t)img * (kMaxLevels + 1) + g.nlevels] = base + T;
+        if (base + T > g.candCap) over = 1;
+    }
+    if (over) atomicOr(overflow, 1);
+    if (base + T > g.candCap) T = g.candCap > base ? g.candCap - base : 0;   // flagged above; stay in bounds
+    __syncthreads();
+
+    const uint32_t *src = cell_kp + ((size_t)img * g.cells + L.cell0) * cap;
+    const int W0 = L.maxBorderX - kMinBorder, H0 = L.maxBorderY - kMinBorder;
+    // pass 1: histogram of path codes
+    for (int i = tid; i < T; i += 1024) {
+        int lo = 0, hi = nc;               // largest c with excl[c] <= i
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (excl[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint32_t p = src[(size_t)lo * cap + (i - excl[lo])];
+        atomicAdd(&hist[path_code(cand_x(p), cand_y(p), W0, H0, L.nIni, L.hX, L.depth)], 1);
+    }
+    __syncthreads();
+    // bucket starts: exclusive scan of the histogram (each thread owns a contiguous run of buckets)
+    {
+        const int bper = (B + 1023) >> 10;
+        const int b0 = tid * bper;
+        int bs = 0;
+        for (int k = 0; k < bper; k++) if (b0 + k < B) bs += hist[b0 + k];
+        int brun = block_exclusive_scan_1024(bs, wsum, &s_tot);
+        for (int k = 0; k < bper; k++) {
+            if (b0 + k < B) { const int v = hist[b0 + k]; hist[b0 + k] = brun; brun += v; }
+        }
+        if (tid == 0) hist[B] = T;
+    }
+    __syncthreads();
+    int *bs_out = bstart + (size_t)img * g.bucketTotal + L.bucket0;
+    for (int b = tid; b <= B; b += 1024) bs_out[b] = hist[b];
+    __syncthreads();
+    // pass 2: scatter into bucket order (device memory), hist[] now counts up from each bucket's start
+    uint32_t *sd = sorted_dev + (size_t)img * g.candCap + base;
+    for (int i = tid; i < T; i += 1024) {
+        int lo = 0, hi = nc;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (excl[mid] <= i) lo = mid; else hi = mid;
+        }
+        const uint32_t p = src[(size_t)lo * cap + (i - excl[lo])];
+        const int slot = atomicAdd(&hist[path_code(cand_x(p), cand_y(p), W0, H0, L.nIni, L.hX, L.depth)], 1);
+        sd[slot] = p;
+    }
+    __syncthreads();   // the workgroup's own global stores are visible to it after the barrier
+    // coalesced copy-out over PCIe into host-mapped memory
+    uint32_t *dst = cand + (size_t)img * g.candCap + base;
+    for (int i = tid; i < T; i += 1024) dst[i] = sd[i];
 }
 
 // ---------------------------------------------------------------------------
 // 7x7 Gaussian, sigma 2, OpenCV >= 4 fixed-point path: taps {18,34,48,56,48,34,18}/256,
 // horizontal pass in 8.8 (u16), vertical pass in 16.16, (sum + 32768) >> 16,
 // BORDER_REFLECT_101 on the un-bordered level (ORBextractor.cpp:1132-1133).
-// Workgroup = 64x16 output tile staged through LDS.
+// Workgroup = 128x32 output tile: aligned dword loads -> LDS, horizontal pass in
+// packed u16 (every partial sum <= 65280, so v_pk_* arithmetic is exact), vertical
+// pass in 32 bits, dword stores.
 // ---------------------------------------------------------------------------
-constexpr int kBlurTW = 64, kBlurTH = 16;
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t load4_reflect(const uint8_t *plane, int pitch, int w, int sy, int x)
+{
+    const uint8_t *row = plane + (size_t)sy * pitch;
+    if (x >= 0 && x + 3 < w) return *reinterpret_cast<const uint32_t *>(row + x);   // x is a multiple of 4
+    uint32_t v = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        int sx = reflect101(x + k, w);
+        sx = sx < 0 ? 0 : (sx >= w ? w - 1 : sx);   // tiles over-cover the right edge; those bytes are never used
+        v |= (uint32_t)row[sx] << (8 * k);
+    }
+    return v;
+}
 
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom g)
 {
-    __shared__ uint8_t in[(kBlurTH + 6) * (kBlurTW + 8)];
-    __shared__ uint16_t hb[(kBlurTH + 6) * kBlurTW];
-    constexpr int IP = kBlurTW + 8;
+    constexpr int TW = kBlurTW, TH = kBlurTH;
+    constexpr int ID = TW / 4 + 2;          // input dwords per row: 4 bytes of apron on each side
+    __shared__ uint32_t in32[(TH + 6) * ID];
+    __shared__ __attribute__((aligned(16))) uint2 hb[(TH + 6) * (TW / 4)];   // 4 x u16 per entry
     const int tid = threadIdx.x;
     const int img = blockIdx.y;
     int level = 0;
@@ -326,35 +542,53 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const LevelGeom &L = g.lv[level];
     const int t = blockIdx.x - L.tile0;
     const int ty = t / L.tilesX, tx = t - ty * L.tilesX;
-    const int x0 = tx * kBlurTW, y0 = ty * kBlurTH;
+    const int x0 = tx * TW, y0 = ty * TH;
     const uint8_t *plane = pyr + (size_t)img * g.imgBytes + L.off;
 
-    for (int i = tid; i < (kBlurTH + 6) * (kBlurTW + 6); i += 256) {
-        const int r = i / (kBlurTW + 6), c = i - r * (kBlurTW + 6);
-        const int sy = reflect101(y0 + r - 3, L.h), sx = reflect101(x0 + c - 3, L.w);
-        // tiles at the right/bottom edge over-cover; clamp keeps the address inside the plane
-        const int cy = sy < 0 ? 0 : (sy >= L.h ? L.h - 1 : sy);
-        const int cx = sx < 0 ? 0 : (sx >= L.w ? L.w - 1 : sx);
-        in[r * IP + c] = plane[(size_t)cy * L.pitch + cx];
+    for (int i = tid; i < (TH + 6) * ID; i += 256) {
+        const int r = i / ID, d = i - r * ID;
+        int sy = reflect101(y0 + r - 3, L.h);
+        sy = sy < 0 ? 0 : (sy >= L.h ? L.h - 1 : sy);
+        in32[i] = load4_reflect(plane, L.pitch, L.w, sy, x0 - 4 + 4 * d);
     }
     __syncthreads();
-    for (int i = tid; i < (kBlurTH + 6) * kBlurTW; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        const uint8_t *s = in + r * IP + c;
-        hb[i] = (uint16_t)(18 * (s[0] + s[6]) + 34 * (s[1] + s[5]) + 48 * (s[2] + s[4]) + 56 * s[3]);
+    // horizontal: work item = (row, group of 4 output pixels); bytes b0..b11 = tile columns 4g .. 4g+11,
+    // output pixel j sits at tile column 4g+4+j and needs b[j+1 .. j+7]
+    for (int i = tid; i < (TH + 6) * (TW / 4); i += 256) {
+        const int r = i / (TW / 4), gx = i - r * (TW / 4);
+        const uint32_t d0 = in32[r * ID + gx], d1 = in32[r * ID + gx + 1], d2 = in32[r * ID + gx + 2];
+#define PK(hi, lo, sel) __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, sel))
+        const u16x2 P1 = PK(d1, d0, 0x0c020c01u), P2 = PK(d1, d0, 0x0c030c02u), P3 = PK(d1, d0, 0x0c040c03u);
+        const u16x2 P4 = PK(d1, d0, 0x0c050c04u), P5 = PK(d1, d0, 0x0c060c05u), P6 = PK(d1, d0, 0x0c070c06u);
+        const u16x2 P7 = PK(d2, d1, 0x0c040c03u), P8 = PK(d2, d1, 0x0c050c04u), P9 = PK(d2, d1, 0x0c060c05u);
+#undef PK
+        const u16x2 k18 = {18, 18}, k34 = {34, 34}, k48 = {48, 48}, k56 = {56, 56};
+        const u16x2 o01 = k18 * (P1 + P7) + k34 * (P2 + P6) + k48 * (P3 + P5) + k56 * P4;
+        const u16x2 o23 = k18 * (P3 + P9) + k34 * (P4 + P8) + k48 * (P5 + P7) + k56 * P6;
+        hb[i] = uint2{__builtin_bit_cast(uint32_t, o01), __builtin_bit_cast(uint32_t, o23)};
     }
     __syncthreads();
-    const int c = tid & 63, rq = tid >> 6;
-    const int x = x0 + c;
+    // vertical: thread = 4 columns x 4 rows, sliding over 10 rows of the horizontal result
+    const int gx = tid & (TW / 4 - 1), rg = tid / (TW / 4);
+    uint32_t h[10][4];
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint2 v = hb[(rg * 4 + r) * (TW / 4) + gx];
+        h[r][0] = v.x & 0xffffu; h[r][1] = v.x >> 16; h[r][2] = v.y & 0xffffu; h[r][3] = v.y >> 16;
+    }
     uint8_t *oplane = blur + (size_t)img * g.imgBytes + L.off;
+    const int x = x0 + 4 * gx;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int r = rq * 4 + k;
-        const uint16_t *s = hb + r * kBlurTW + c;
-        const uint32_t acc = 18u * (s[0] + s[6 * kBlurTW]) + 34u * (s[kBlurTW] + s[5 * kBlurTW]) +
-                             48u * (s[2 * kBlurTW] + s[4 * kBlurTW]) + 56u * s[3 * kBlurTW];
-        const int y = y0 + r;
-        if (x < L.w && y < L.h) oplane[(size_t)y * L.pitch + x] = (uint8_t)((acc + 32768u) >> 16);
+        uint32_t out = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t acc = 18u * (h[k][j] + h[k + 6][j]) + 34u * (h[k + 1][j] + h[k + 5][j]) +
+                                 48u * (h[k + 2][j] + h[k + 4][j]) + 56u * h[k + 3][j];
+            out |= ((acc + 32768u) >> 16) << (8 * j);
+        }
+        const int y = y0 + rg * 4 + k;
+        if (x < L.w && y < L.h) *reinterpret_cast<uint32_t *>(oplane + (size_t)y * L.pitch + x) = out;
     }
 }
 
@@ -470,6 +704,19 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
 // "two smallest keys" exactly knnMatch's order, including its lowest-index
 // tie-break, so chunks can be reduced in any order.
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ void knn_insert(uint32_t key, uint32_t &k0, uint32_t &k1)
+{
+    const uint32_t lo = key < k0 ? key : k0;
+    const uint32_t hi = key < k0 ? k0 : key;
+    k1 = hi < k1 ? hi : k1;
+    k0 = lo;
+}
+
+// kKnnQpl queries per lane (q, q+64, ...): every broadcast LDS read of a train descriptor feeds
+// kKnnQpl distance evaluations, which divides the LDS traffic per distance and gives each wave
+// kKnnQpl independent dependency chains.
+constexpr int kKnnQpl = 1;
+
 __global__ __launch_bounds__(64) void k_knn2(const uint8_t *__restrict__ desc, const int *__restrict__ counts,
                                              const int2 *__restrict__ pairs, int kcap, int nchunks,
                                              uint2 *__restrict__ part)
@@ -479,29 +726,38 @@ __global__ __launch_bounds__(64) void k_knn2(const uint8_t *__restrict__ desc, c
     const int pair = blockIdx.z, chunk = blockIdx.y;
     const int2 qt = pairs[pair];
     const int nq = counts[qt.x], nt = counts[qt.y];
-    const int q = blockIdx.x * 64 + lane;
+    const int q0 = blockIdx.x * (64 * kKnnQpl) + lane;
     const int t0 = chunk * kKnnChunk;
-    if (blockIdx.x * 64 >= nq) return;
-    uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu;
+    if (blockIdx.x * (64 * kKnnQpl) >= nq) return;
+    uint32_t k0[kKnnQpl], k1[kKnnQpl];
+#pragma unroll
+    for (int u = 0; u < kKnnQpl; u++) k0[u] = k1[u] = 0xffffffffu;
     if (t0 < nt) {
         const int tn = nt - t0 < kKnnChunk ? nt - t0 : kKnnChunk;
         const ulonglong4 *tsrc = reinterpret_cast<const ulonglong4 *>(desc + ((size_t)qt.y * kcap + t0) * 32);
         for (int i = lane; i < tn; i += 64) tr[i] = tsrc[i];
         __syncthreads();
-        ulonglong4 qv = {0, 0, 0, 0};
-        if (q < nq) qv = *reinterpret_cast<const ulonglong4 *>(desc + ((size_t)qt.x * kcap + q) * 32);
-#pragma unroll 4
+        ulonglong4 v[kKnnQpl];
+#pragma unroll
+        for (int u = 0; u < kKnnQpl; u++) {
+            v[u] = ulonglong4{0, 0, 0, 0};
+            if (q0 + 64 * u < nq) v[u] = *reinterpret_cast<const ulonglong4 *>(desc + ((size_t)qt.x * kcap + q0 + 64 * u) * 32);
+        }
+#pragma unroll 2
         for (int j = 0; j < tn; j++) {
             const ulonglong4 t = tr[j];
-            const uint32_t d = __popcll(qv.x ^ t.x) + __popcll(qv.y ^ t.y) + __popcll(qv.z ^ t.z) + __popcll(qv.w ^ t.w);
-            const uint32_t key = (d << 16) | (uint32_t)(t0 + j);
-            const uint32_t lo = key < k0 ? key : k0;
-            const uint32_t hi = key < k0 ? k0 : key;
-            k1 = hi < k1 ? hi : k1;
-            k0 = lo;
+            const uint32_t tj = (uint32_t)(t0 + j);
+#pragma unroll
+            for (int u = 0; u < kKnnQpl; u++) {
+                const uint32_t d = __popcll(v[u].x ^ t.x) + __popcll(v[u].y ^ t.y) + __popcll(v[u].z ^ t.z) + __popcll(v[u].w ^ t.w);
+                knn_insert((d << 16) | tj, k0[u], k1[u]);
+            }
         }
     }
-    if (q < nq) part[((size_t)pair * nchunks + chunk) * kcap + q] = uint2{k0, k1};
+    uint2 *out = part + ((size_t)pair * nchunks + chunk) * kcap;
+#pragma unroll
+    for (int u = 0; u < kKnnQpl; u++)
+        if (q0 + 64 * u < nq) out[q0 + 64 * u] = uint2{k0[u], k1[u]};
 }
 
 // Merge chunk partials, emit the knnMatch table and BruteForceMatch's accept
@@ -528,17 +784,16 @@ __global__ __launch_bounds__(256) void k_knn2_finalize(const uint2 *__restrict__
         lo = key < k0 ? key : k0; hi = key < k0 ? k0 : key;
         k1 = hi < k1 ? hi : k1; k0 = lo;
     }
-    KnnRow r;
-    r.idx0 = k0 == 0xffffffffu ? -1 : (int)(k0 & 0xffffu);
-    r.idx1 = k1 == 0xffffffffu ? -1 : (int)(k1 & 0xffffu);
-    r.d0 = k0 == 0xffffffffu ? -1 : (int)(k0 >> 16);
-    r.d1 = k1 == 0xffffffffu ? -1 : (int)(k1 >> 16);
-    int acc = 0;
-    if (r.idx0 >= 0 && r.idx1 >= 0) {
-        const float f0 = (float)r.d0, f1 = (float)r.d1;
+    const bool v0 = k0 != 0xffffffffu, v1 = k1 != 0xffffffffu;
+    const uint32_t d0 = v0 ? k0 >> 16 : 0u, d1 = v1 ? k1 >> 16 : 0u;
+    uint32_t acc = 0;
+    if (v0 && v1) {
+        const float f0 = (float)d0, f1 = (float)d1;   // DMatch::distance is float
         acc = (f0 < __fmul_rn(ratio, f1)) && !(f0 > dist_thresh);
     }
-    r.d1 |= acc << 30;
+    KnnRow r;
+    r.idx = (v0 ? (k0 & 0xffffu) : 0xffffu) | ((v1 ? (k1 & 0xffffu) : 0xffffu) << 16);
+    r.d = d0 | (d1 << 9) | (acc << 18);
     out[(size_t)pair * kcap + q] = r;
 }
 
@@ -554,21 +809,41 @@ void launch_stage_f32(hipStream_t st, const float *src, int w, int h, int pitch_
     hipLaunchKernelGGL(k_stage_f32, grid, dim3(256), 0, st, src, w, h, pitch_f, channels, img_stride_f, pyr, g);
 }
 
-void launch_pyramid(hipStream_t st, uint8_t *pyr, const Geom &g, const ResizeTap *tabs, int nimg)
+void launch_pyramid(hipStream_t st, uint8_t *pyr, const Geom &g, const ResizeTap *tabs, const int *win, int nimg)
 {
     for (int l = 1; l < g.nlevels; l++) {
         dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, nimg);
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, st, pyr, g, l, tabs);
+        const int srcPitch = win[2 * l], srcRows = win[2 * l + 1];   // LDS window, sized on the host from the tables
+        hipLaunchKernelGGL(k_resize, grid, dim3(256), (size_t)srcPitch * srcRows, st, pyr, g, l, tabs, srcPitch, srcRows);
     }
 }
 
 void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, uint32_t *cell_kp,
-                 int *cell_cnt, uint32_t *cand, int *lvl_off, int *overflow, int nimg, hipEvent_t ev_mid)
+                 int *cell_cnt, int nimg)
 {
     dim3 grid(g.cells, nimg);
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, st, pyr, g, iniTh, minTh, cell_kp, cell_cnt);
-    if (ev_mid) (void)hipEventRecord(ev_mid, st);
-    hipLaunchKernelGGL(k_compact, grid, dim3(256), 0, st, cell_kp, cell_cnt, g, cand, lvl_off, overflow);
+    // LDS per cell: ROI rows x dword-aligned pitch (3 phase bytes + wCell + 6), for the tile and for the score map
+    int tileBytes = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int tb = (g.lv[l].hCell + 6) * (((3 + g.lv[l].wCell + 6 + 3) >> 2) << 2);
+        tileBytes = tileBytes > tb ? tileBytes : tb;
+    }
+    tileBytes = (tileBytes + 15) & ~15;
+    hipLaunchKernelGGL(k_fast_cells, grid, dim3(64), 4 * tileBytes, st, pyr, g, iniTh, minTh, tileBytes, cell_kp,
+                       cell_cnt);
+}
+
+void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt, const Geom &g, uint32_t *sorted_dev,
+                    uint32_t *cand, int *lvl_off, int *bstart, int *overflow, int nimg)
+{
+    int maxc = 1, maxb = 1;
+    for (int l = 0; l < g.nlevels; l++) {
+        maxc = maxc > g.lv[l].nCols * g.lv[l].nRows ? maxc : g.lv[l].nCols * g.lv[l].nRows;
+        maxb = maxb > g.lv[l].nBuckets ? maxb : g.lv[l].nBuckets;
+    }
+    const int exclCap = (maxc + 1 + 3) & ~3;
+    hipLaunchKernelGGL(k_compact, dim3(g.nlevels, nimg), dim3(1024), (size_t)(exclCap + maxb + 1) * sizeof(int), st, cell_kp,
+                       cell_cnt, g, sorted_dev, cand, lvl_off, bstart, overflow, exclCap);
 }
 
 void launch_blur(hipStream_t st, const uint8_t *pyr, uint8_t *blur, const Geom &g, int nimg)
@@ -588,7 +863,7 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
                  uint2 *part, float dist_thresh, float ratio, KnnRow *out, hipEvent_t ev_mid)
 {
     const int nchunks = (kcap + kKnnChunk - 1) / kKnnChunk;
-    dim3 grid((kcap + 63) / 64, nchunks, npairs);
+    dim3 grid((kcap + 64 * kKnnQpl - 1) / (64 * kKnnQpl), nchunks, npairs);
     hipLaunchKernelGGL(k_knn2, grid, dim3(64), 0, st, desc, counts, pairs, kcap, nchunks, part);
     if (ev_mid) (void)hipEventRecord(ev_mid, st);
     dim3 g2((kcap + 255) / 256, npairs);

@@ -1,14 +1,15 @@
-// mcorb_select.cpp -- host stage: quad-tree keypoint selection.
+// mcorb_select.cpp -- host stage: quad-tree keypoint selection on GPU-bucketed candidates.
 //
-// Functional equivalent of ORBextractor::DistributeOctTree + ExtractorNode::
-// DivideNode + compareNodes (MCSlam/src/ORBextractor.cpp:479-778), rebuilt for
-// speed: keys are indices into the packed candidate list, node key sets are
-// ranges of an append-only arena, the node list is an index-linked list.  The
-// reference's result is order-defined by (a) std::list push_front/erase order
-// and (b) std::sort's placement of equivalent (count, UL.x) entries, so this
-// stage keeps the same list discipline and calls std::sort on the same sequence
-// with the same predicate.  It is serial per (image, level) and runs on the
-// engine's worker pool between the two GPU phases.
+// Functional equivalent of ORBextractor::DistributeOctTree + ExtractorNode::DivideNode +
+// compareNodes (MCSlam/src/ORBextractor.cpp:479-778).  The reference's result is order-defined
+// by (a) std::list push_front/erase order and (b) std::sort's placement of equivalent
+// (count, UL.x) entries, so the LIST DISCIPLINE stays here, on the host, and std::sort is called
+// on the same sequence with the same predicate.  What moved to the GPU is the data-parallel part:
+// k_compact sorts each level's candidates by quad-tree path code (path_code(), mcorb_common.h)
+// and ships the bucket start offsets, so for the first `depth` splits a node's key set is a
+// contiguous range whose size is one subtraction; deeper nodes (a handful of keys each) are
+// partitioned here.  The final "max response, first one wins" pick (:757-775) resolves ties from
+// the coordinates, which encode vToDistributeKeys order (cell row, cell col, y, x).
 #include "mcorb_select.h"
 
 #include <math.h>
@@ -21,7 +22,10 @@ namespace mcorb {
 namespace {
 struct Node {
     int x0, y0, x1, y1;   // UL = (x0,y0), BR = (x1,y1); UR/BL follow (nodes stay rectangles)
-    int kbeg, kcnt;       // key range in the arena
+    int d;                // depth below the root
+    uint32_t code;        // path code prefix (root index, then 2 bits per split)
+    int beg, cnt;         // key range: in the sorted candidate array (arena == false) or in the arena
+    bool arena;
     int prev, next;
     bool noMore;
 };
@@ -63,28 +67,39 @@ struct SelectScratch::Impl {
 SelectScratch::SelectScratch() : impl(new Impl) {}
 SelectScratch::~SelectScratch() { delete impl; }
 
-// DivideNode (:479-535): splits node `id` into up to four children appended to
-// the arena in n1..n4 order; returns child ids (-1 where a child has no keys).
-static void divide(SelectScratch::Impl &S, const uint32_t *cand, int id, int child[4])
+// DivideNode (:479-535): children in n1..n4 order; child[q] = -1 where a child has no keys.
+static void divide(SelectScratch::Impl &S, const uint32_t *cand, const int *bstart, int D, int id, int child[4])
 {
     const Node P = S.nodes[id];
-    const int halfX = (int)ceilf((float)(P.x1 - P.x0) / 2);
-    const int halfY = (int)ceilf((float)(P.y1 - P.y0) / 2);
-    const int sx = P.x0 + halfX, sy = P.y0 + halfY;
-    int cnt[4] = {0, 0, 0, 0};
-    if ((int)S.quad.size() < P.kcnt) S.quad.resize(P.kcnt);
-    for (int i = 0; i < P.kcnt; i++) {
-        const uint32_t c = cand[S.arena[P.kbeg + i]];
-        // kp.pt.x < n1.UR.x ? (kp.pt.y < n1.BR.y ? n1 : n3) : (kp.pt.y < n1.BR.y ? n2 : n4)
-        const int q = (cand_x(c) < sx ? 0 : 1) + (cand_y(c) < sy ? 0 : 2);
-        S.quad[i] = (uint8_t)q;
-        cnt[q]++;
+    const int sx = P.x0 + ((P.x1 - P.x0 + 1) >> 1);   // UL.x + ceil((UR.x-UL.x)/2)
+    const int sy = P.y0 + ((P.y1 - P.y0 + 1) >> 1);
+    int cnt[4], beg[4];
+    bool in_arena = false;
+    if (P.d < D) {
+        // children are bucket ranges of the GPU-sorted array
+        const int shift = 2 * (D - P.d - 1);
+        for (int q = 0; q < 4; q++) {
+            const uint32_t c = (P.code << 2) | (uint32_t)q;
+            beg[q] = bstart[c << shift];
+            cnt[q] = bstart[(c + 1) << shift] - beg[q];
+        }
+    } else {
+        in_arena = true;
+        cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+        if ((int)S.quad.size() < P.cnt) S.quad.resize(P.cnt);
+        for (int i = 0; i < P.cnt; i++) {
+            const uint32_t c = cand[P.arena ? S.arena[P.beg + i] : P.beg + i];
+            // kp.pt.x < n1.UR.x ? (kp.pt.y < n1.BR.y ? n1 : n3) : (kp.pt.y < n1.BR.y ? n2 : n4)
+            const int q = (cand_x(c) < sx ? 0 : 1) + (cand_y(c) < sy ? 0 : 2);
+            S.quad[i] = (uint8_t)q;
+            cnt[q]++;
+        }
+        const size_t base = S.arena.size();
+        S.arena.resize(base + P.cnt);
+        beg[0] = (int)base; beg[1] = beg[0] + cnt[0]; beg[2] = beg[1] + cnt[1]; beg[3] = beg[2] + cnt[2];
+        int pos[4] = {beg[0], beg[1], beg[2], beg[3]};
+        for (int i = 0; i < P.cnt; i++) S.arena[pos[S.quad[i]]++] = P.arena ? S.arena[P.beg + i] : P.beg + i;
     }
-    const size_t base = S.arena.size();
-    S.arena.resize(base + P.kcnt);
-    int pos[4] = {(int)base, (int)base + cnt[0], (int)base + cnt[0] + cnt[1], (int)base + cnt[0] + cnt[1] + cnt[2]};
-    const int beg[4] = {pos[0], pos[1], pos[2], pos[3]};
-    for (int i = 0; i < P.kcnt; i++) S.arena[pos[S.quad[i]]++] = S.arena[P.kbeg + i];
     const int bx0[4] = {P.x0, sx, P.x0, sx}, bx1[4] = {sx, P.x1, sx, P.x1};
     const int by0[4] = {P.y0, P.y0, sy, sy}, by1[4] = {sy, sy, P.y1, P.y1};
     for (int q = 0; q < 4; q++) {
@@ -93,58 +108,47 @@ static void divide(SelectScratch::Impl &S, const uint32_t *cand, int id, int chi
         const int c = S.new_node();
         Node &n = S.nodes[c];
         n.x0 = bx0[q]; n.x1 = bx1[q]; n.y0 = by0[q]; n.y1 = by1[q];
-        n.kbeg = beg[q]; n.kcnt = cnt[q];
+        n.d = P.d + 1;
+        n.code = (P.code << 2) | (uint32_t)q;
+        n.beg = beg[q]; n.cnt = cnt[q];
+        n.arena = in_arena;
         n.noMore = (cnt[q] == 1);
         child[q] = c;
     }
 }
 
-int select_octree(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N, int *out_idx,
+int select_octree(const uint32_t *cand, const int *bstart, int n, const SelectParams &P, int *out_idx,
                   SelectScratch &scratch)
 {
     SelectScratch::Impl &S = *scratch.impl;
     S.nodes.clear(); S.arena.clear(); S.expand.clear(); S.prevExpand.clear();
     S.head = S.tail = -1; S.count = 0;
-    S.nodes.reserve(4 * (size_t)(N > 64 ? N : 64) + 64);
-    S.arena.reserve((size_t)n * 12 + 64);
+    const int N = P.N, D = P.depth;
+    if (P.nIni < 1) return -2;
+    if (n <= 0) return 0;
+    const float hX = P.hX;
 
-    const int nIni = (int)roundf((float)(maxX - minX) / (maxY - minY));
-    if (nIni < 1) return -2;
-    const float hX = (float)(maxX - minX) / nIni;
-
-    // root nodes (:567-578) and key assignment (:581-585), stable by construction
-    std::vector<int> rootCnt(nIni, 0);
-    if ((int)S.quad.size() < n) S.quad.resize(n);
-    std::vector<int> rootOf(n);
-    for (int i = 0; i < n; i++) {
-        int r = (int)((float)cand_x(cand[i]) / hX);
-        if (r >= nIni) r = nIni - 1;   // the reference would index out of range here; cannot happen for x < maxX-minX
-        rootOf[i] = r;
-        rootCnt[r]++;
-    }
-    S.arena.resize(n);
-    std::vector<int> rootPos(nIni, 0);
-    for (int r = 1; r < nIni; r++) rootPos[r] = rootPos[r - 1] + rootCnt[r - 1];
-    {
-        std::vector<int> p = rootPos;
-        for (int i = 0; i < n; i++) S.arena[p[rootOf[i]]++] = i;
-    }
-    for (int i = 0; i < nIni; i++) {
+    // root nodes (:567-578); their key sets are the top-level bucket ranges
+    for (int i = 0; i < P.nIni; i++) {
         const int id = S.new_node();
         Node &nd = S.nodes[id];
         nd.x0 = (int)(hX * (float)i);
         nd.x1 = (int)(hX * (float)(i + 1));
         nd.y0 = 0;
-        nd.y1 = maxY - minY;
-        nd.kbeg = rootPos[i]; nd.kcnt = rootCnt[i];
+        nd.y1 = P.maxY - P.minY;
+        nd.d = 0;
+        nd.code = (uint32_t)i;
+        nd.beg = bstart[(uint32_t)i << (2 * D)];
+        nd.cnt = bstart[(uint32_t)(i + 1) << (2 * D)] - nd.beg;
+        nd.arena = false;
         nd.noMore = false;
         S.push_back(id);
     }
     // (:587-600)
     for (int it = S.head; it >= 0;) {
         Node &nd = S.nodes[it];
-        if (nd.kcnt == 1) { nd.noMore = true; it = nd.next; }
-        else if (nd.kcnt == 0) it = S.erase(it);
+        if (nd.cnt == 1) { nd.noMore = true; it = nd.next; }
+        else if (nd.cnt == 0) it = S.erase(it);
         else it = nd.next;
     }
 
@@ -156,13 +160,13 @@ int select_octree(const uint32_t *cand, int n, int minX, int maxX, int minY, int
         for (int it = S.head; it >= 0;) {
             if (S.nodes[it].noMore) { it = S.nodes[it].next; continue; }
             int ch[4];
-            divide(S, cand, it, ch);
+            divide(S, cand, bstart, D, it, ch);
             for (int q = 0; q < 4; q++) {
                 if (ch[q] < 0) continue;
                 S.push_front(ch[q]);
-                if (S.nodes[ch[q]].kcnt > 1) {
+                if (S.nodes[ch[q]].cnt > 1) {
                     nToExpand++;
-                    S.expand.emplace_back(S.nodes[ch[q]].kcnt, ch[q]);
+                    S.expand.emplace_back(S.nodes[ch[q]].cnt, ch[q]);
                 }
             }
             it = S.erase(it);
@@ -185,11 +189,11 @@ int select_octree(const uint32_t *cand, int n, int minX, int maxX, int minY, int
                 for (int j = (int)S.prevExpand.size() - 1; j >= 0; j--) {
                     const int id = S.prevExpand[j].second;
                     int ch[4];
-                    divide(S, cand, id, ch);
+                    divide(S, cand, bstart, D, id, ch);
                     for (int q = 0; q < 4; q++) {
                         if (ch[q] < 0) continue;
                         S.push_front(ch[q]);
-                        if (S.nodes[ch[q]].kcnt > 1) S.expand.emplace_back(S.nodes[ch[q]].kcnt, ch[q]);
+                        if (S.nodes[ch[q]].cnt > 1) S.expand.emplace_back(S.nodes[ch[q]].cnt, ch[q]);
                     }
                     S.erase(id);
                     if (S.count >= N) break;
@@ -199,20 +203,65 @@ int select_octree(const uint32_t *cand, int n, int minX, int maxX, int minY, int
         }
     }
 
-    // best response per node, first maximum wins (:757-775)
+    // best response per node; among equal responses the first key in vToDistributeKeys order wins
+    // (:757-775), i.e. the smallest (cell row, cell col, y, x)
     int m = 0;
     for (int it = S.head; it >= 0; it = S.nodes[it].next) {
         const Node &nd = S.nodes[it];
-        int best = S.arena[nd.kbeg];
-        int bestR = cand_resp(cand[best]);
-        for (int k = 1; k < nd.kcnt; k++) {
-            const int idx = S.arena[nd.kbeg + k];
-            const int r = cand_resp(cand[idx]);
-            if (r > bestR) { bestR = r; best = idx; }
+        int best = -1, bestR = -1;
+        uint64_t bestO = 0;
+        for (int k = 0; k < nd.cnt; k++) {
+            const int idx = nd.arena ? S.arena[nd.beg + k] : nd.beg + k;
+            const uint32_t c = cand[idx];
+            const int r = cand_resp(c);
+            if (r < bestR) continue;
+            const int x = cand_x(c), y = cand_y(c);
+            const uint64_t o = ((((uint64_t)((y - 3) / P.hCell) << 12 | (uint64_t)((x - 3) / P.wCell)) << 12 | (uint64_t)y) << 12) |
+                               (uint64_t)x;
+            if (r > bestR || o < bestO) { bestR = r; best = idx; bestO = o; }
         }
         out_idx[m++] = best;
     }
     return m;
+}
+
+// CPU statement of what k_compact does on the GPU for one level (used by the host-only test hook):
+// counting sort of the candidates by path code, bucket starts out.
+void host_bucket_sort(const uint32_t *cand, int n, const SelectParams &P, std::vector<uint32_t> &sorted,
+                      std::vector<int> &perm, std::vector<int> &bstart)
+{
+    const int B = P.nIni << (2 * P.depth);
+    bstart.assign((size_t)B + 1, 0);
+    std::vector<uint32_t> code(n);
+    const int W0 = P.maxX - P.minX, H0 = P.maxY - P.minY;
+    for (int i = 0; i < n; i++) {
+        code[i] = path_code(cand_x(cand[i]), cand_y(cand[i]), W0, H0, P.nIni, P.hX, P.depth);
+        bstart[code[i] + 1]++;
+    }
+    for (int b = 0; b < B; b++) bstart[b + 1] += bstart[b];
+    std::vector<int> pos(bstart.begin(), bstart.end() - 1);
+    sorted.resize(n);
+    perm.resize(n);
+    for (int i = 0; i < n; i++) {
+        const int s = pos[code[i]]++;
+        sorted[s] = cand[i];
+        perm[s] = i;
+    }
+}
+
+SelectParams make_select_params(int minX, int maxX, int minY, int maxY, int N, int wCell, int hCell)
+{
+    SelectParams P;
+    P.minX = minX; P.maxX = maxX; P.minY = minY; P.maxY = maxY; P.N = N;
+    P.wCell = wCell > 0 ? wCell : (1 << 20);
+    P.hCell = hCell > 0 ? hCell : (1 << 20);
+    P.nIni = (int)roundf((float)(maxX - minX) / (maxY - minY));   // (:558)
+    P.hX = P.nIni >= 1 ? (float)(maxX - minX) / P.nIni : 0.f;      // (:560)
+    // depth of the GPU bucketing: about log4(N / nIni), i.e. where a uniform spread reaches the quota
+    int d = 1;
+    while (d < 5 && (P.nIni > 0 ? P.nIni : 1) * (1 << (2 * d)) < N) d++;
+    P.depth = d;
+    return P;
 }
 
 }  // namespace mcorb

@@ -16,11 +16,26 @@ struct SelectScratch {
     SelectScratch &operator=(const SelectScratch &) = delete;
 };
 
-// cand: packed candidates of one (image, level) in vToDistributeKeys order.
-// out_idx: indices of the retained candidates in the reference's result order;
-// needs room for N + 4 entries.  Returns the count, or -2 if the level is too
-// tall for a root node (the reference divides by zero there).
-int select_octree(const uint32_t *cand, int n, int minX, int maxX, int minY, int maxY, int N, int *out_idx,
+// per-level constants of DistributeOctTree's call (ORBextractor.cpp:876-877) plus the bucketing depth
+struct SelectParams {
+    int minX, maxX, minY, maxY;   // (:788-791)
+    int N;                        // mnFeaturesPerLevel[level]
+    int nIni;                     // (:558)
+    float hX;                     // (:560)
+    int depth;                    // path-code depth used by k_compact for this level
+    int wCell, hCell;             // cell grid of the detection loop: recovers vToDistributeKeys order from (x,y)
+};
+SelectParams make_select_params(int minX, int maxX, int minY, int maxY, int N, int wCell, int hCell);
+
+// cand: one level's candidates sorted by path code (any order inside a bucket); bstart: the
+// nIni*4^depth + 1 bucket start offsets.  out_idx: indices INTO cand of the retained candidates
+// in the reference's result order; needs room for N + 64 entries.  Returns the count, or -2 if
+// the level is too tall for a root node (the reference divides by zero there).
+int select_octree(const uint32_t *cand, const int *bstart, int n, const SelectParams &P, int *out_idx,
                   SelectScratch &scratch);
+
+// host statement of k_compact's counting sort for one level (test hook only)
+void host_bucket_sort(const uint32_t *cand, int n, const SelectParams &P, std::vector<uint32_t> &sorted,
+                      std::vector<int> &perm, std::vector<int> &bstart);
 
 }  // namespace mcorb

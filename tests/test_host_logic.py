@@ -60,10 +60,11 @@ def _pack(x, y, r):
     return (y.astype(np.uint32) << 20) | (x.astype(np.uint32) << 8) | r.astype(np.uint32)
 
 
-def _select(x, y, r, W, H, N):
+def _select(x, y, r, W, H, N, wcell=0, hcell=0):
     packed = _pack(x, y, r)
     out = np.zeros(N + 80, np.int32)
-    n = L.mcorb_host_select(packed.ctypes.data, len(packed), 16, W - 16, 16, H - 16, N, out.ctypes.data, len(out))
+    n = L.mcorb_host_select(packed.ctypes.data, len(packed), 16, W - 16, 16, H - 16, N, wcell, hcell,
+                            out.ctypes.data, len(out))
     return n, out[:max(n, 0)]
 
 
@@ -91,23 +92,26 @@ def test_selection_stage_on_real_fast_candidates():
     ex = O.OracleExtractor(1000)
     ex(img)
     t = ex.tables()
+    six = np.zeros((8, 6), np.int32)
+    assert L.mcorb_host_geometry(C.byref(_lib.default_params(nfeatures=1000)), 640, 480, six.ctypes.data) == 0
     for l in range(8):
-        x, y, r = ex.candidates(l)
+        x, y, r = ex.candidates(l)          # vToDistributeKeys order: cell row, cell col, then raster
         lw, lh = ex.level_size(l, 640, 480)
         n_o, idx_o = O.distribute_octree(x, y, r, 16, lw - 16, 16, lh - 16, int(t["quota"][l]))
-        n_p, idx_p = _select(x.astype(np.int32), y.astype(np.int32), r.astype(np.int32), lw, lh, int(t["quota"][l]))
+        n_p, idx_p = _select(x.astype(np.int32), y.astype(np.int32), r.astype(np.int32), lw, lh, int(t["quota"][l]),
+                             int(six[l, 4]), int(six[l, 5]))
         assert n_p == n_o and np.array_equal(idx_p, idx_o), "level %d" % l
 
 
 def test_selection_edge_cases():
-    assert L.mcorb_host_select(None, 0, 16, 600, 16, 400, 10, np.zeros(4, np.int32).ctypes.data, 4) == 0
+    assert L.mcorb_host_select(None, 0, 16, 600, 16, 400, 10, 0, 0, np.zeros(4, np.int32).ctypes.data, 4) == 0
     x = np.array([5], np.int32); y = np.array([7], np.int32); r = np.array([30], np.int32)
     n, idx = _select(x, y, r, 640, 480, 100)
     assert n == 1 and idx.tolist() == [0]
     # too tall a level -> the reference has no root node
     out = np.zeros(8, np.int32)
     p = _pack(x, y, r)
-    assert L.mcorb_host_select(p.ctypes.data, 1, 16, 116, 16, 416, 10, out.ctypes.data, 8) == _lib.E_SIZE
+    assert L.mcorb_host_select(p.ctypes.data, 1, 16, 116, 16, 416, 10, 0, 0, out.ctypes.data, 8) == _lib.E_SIZE
 
 
 def test_hamming256_matches_reference_swar():
