@@ -85,8 +85,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=8, help="rig frames per rank per step")
-    ap.add_argument("--slots", type=int, default=2, help="sub-batches in flight per rank")
+    ap.add_argument("--frames", type=int, default=32, help="rig frames per rank per step")
+    ap.add_argument("--slots", type=int, default=4, help="sub-batches in flight per rank")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); 'gloo' only to rehearse N>1 on a 1-GPU box")

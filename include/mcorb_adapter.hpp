@@ -1,0 +1,269 @@
+// mcorb_adapter.hpp -- header-only C++ host mirror of the reference interfaces this path
+// replaces, on top of the C ABI (mcorb.h).  Same names, argument meaning and error behaviour as
+//   class ORBextractor                          MCSlam/include/MCSlam/ORBextractor.h:43-116
+//   MultiCameraFrame::extractFeaturesParallel   MCSlam/include/MCSlam/MultiCameraFrame.h:74
+//   MultiCameraFrame::BruteForceMatch           MultiCameraFrame.h:86
+//   MultiCameraFrame::computeIntraMatches       MultiCameraFrame.h:84
+//   class IntraMatch                            MultiCameraFrame.h:42-57
+//
+// Two flavours in one header:
+//   * plain types (std::vector, raw pointers) -- compiles anywhere, used by tests/cpp;
+//   * with -DMCORB_WITH_OPENCV the exact cv:: signatures of the reference are added, so that
+//     MCSlam/src/ORBextractor.cpp can be dropped from the build and this header included from
+//     MCSlam/include/MCSlam/ORBextractor.h instead.
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <array>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mcorb.h"
+
+#ifdef MCORB_WITH_OPENCV
+#include <opencv2/core/core.hpp>
+#include <opencv2/features2d/features2d.hpp>
+#endif
+
+namespace mcorb {
+
+const int TH_HIGH = 100;      // ORBextractor.h:26
+const int TH_LOW = 75;        // ORBextractor.h:27
+const int HISTO_LENGTH = 30;  // ORBextractor.h:28
+
+inline void check(int st, const char *what)
+{
+    if (st != MCORB_OK) throw std::runtime_error(std::string(what) + ": " + mcorb_last_error());
+}
+
+class ORBextractor {
+public:
+    enum { HARRIS_SCORE = 0, FAST_SCORE = 1 };
+
+    ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int device = 0)
+    {
+        mcorb_default_params(&p_);
+        p_.nfeatures = nfeatures; p_.scale_factor = scaleFactor; p_.nlevels = nlevels;
+        p_.ini_th_fast = iniThFAST; p_.min_th_fast = minThFAST; p_.device_id = device;
+        mvScaleFactor.resize(nlevels); mvInvScaleFactor.resize(nlevels);
+        mvLevelSigma2.resize(nlevels); mvInvLevelSigma2.resize(nlevels); mnFeaturesPerLevel.resize(nlevels);
+        check(mcorb_get_tables(&p_, mvScaleFactor.data(), mvInvScaleFactor.data(), mvLevelSigma2.data(),
+                               mvInvLevelSigma2.data(), mnFeaturesPerLevel.data()), "mcorb_get_tables");
+        check(mcorb_create(&p_, 0, 0, &h_), "mcorb_create");
+    }
+    ~ORBextractor() { mcorb_destroy(h_); }
+    ORBextractor(const ORBextractor &) = delete;
+    ORBextractor &operator=(const ORBextractor &) = delete;
+
+    // operator() on plain buffers.  Returns monoIndex, or -1 for an empty image exactly like the
+    // reference (ORBextractor.cpp:1090-1091); throws on the conditions where the reference would
+    // divide by zero or assert.  The reference ignores its mask argument; it has none here.
+    int operator()(const uint8_t *gray, int w, int h, int stride, std::vector<mcorb_keypoint> &_keypoints,
+                   std::vector<uint8_t> &_descriptors, std::vector<int> &vLappingArea)
+    {
+        const int cap = p_.nfeatures + 8 * p_.nlevels + 64;
+        _keypoints.resize(cap);
+        _descriptors.resize((size_t)cap * 32);
+        int n = 0, mono = 0;
+        const int lap0 = vLappingArea.size() > 0 ? vLappingArea[0] : 0, lap1 = vLappingArea.size() > 1 ? vLappingArea[1] : 0;
+        const int st = mcorb_extract(h_, gray, w, h, stride, lap0, lap1, _keypoints.data(), _descriptors.data(), cap, &n, &mono);
+        if (st == MCORB_E_EMPTY) { _keypoints.clear(); _descriptors.clear(); return -1; }
+        check(st, "mcorb_extract");
+        _keypoints.resize(n);
+        _descriptors.resize((size_t)n * 32);
+        return mono;
+    }
+
+    int inline GetLevels() { return p_.nlevels; }
+    float inline GetScaleFactor() { return p_.scale_factor; }
+    std::vector<float> inline GetScaleFactors() { return mvScaleFactor; }
+    std::vector<float> inline GetInverseScaleFactors() { return mvInvScaleFactor; }
+    std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
+    std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
+
+    // DescriptorDistance (ORBextractor.cpp:1202-1218) on 32-byte rows
+    int DescriptorDistance(const uint8_t *a, const uint8_t *b) { return mcorb_hamming256(a, b); }
+
+    // knnMatch(k=2) + the ratio / threshold filter of BruteForceMatch (MultiCameraFrame.cpp:1053-1078)
+    void BruteForceMatch(const uint8_t *d1, int n1, const uint8_t *d2, int n2, float dist_thresh, float neigh_ratio,
+                         std::vector<unsigned int> &indices_1, std::vector<unsigned int> &indices_2)
+    {
+        indices_1.assign(n1 > 0 ? n1 : 0, 0);
+        indices_2.assign(n1 > 0 ? n1 : 0, 0);
+        int n = 0;
+        check(mcorb_match_ratio(h_, d1, n1, d2, n2, dist_thresh, neigh_ratio, indices_1.data(), indices_2.data(), n1, &n),
+              "mcorb_match_ratio");
+        indices_1.resize(n);
+        indices_2.resize(n);
+    }
+
+    // getMatches_distRatio (ORBextractor.cpp:1228-1290): best / second-best over index subsets on the
+    // GPU k-NN kernel, then the reference's one-to-one bookkeeping.  A and B are n x 32 row-major.
+    void getMatches_distRatio(const uint8_t *A, const std::vector<unsigned int> &i_A, const uint8_t *B,
+                              const std::vector<unsigned int> &i_B, std::vector<unsigned int> &i_match_A,
+                              std::vector<unsigned int> &i_match_B, int &BookK)
+    {
+        i_match_A.resize(0);
+        i_match_B.resize(0);
+        BookK += (int)(i_A.size() * i_B.size());
+        if (i_A.empty() || i_B.empty()) return;
+        std::vector<uint8_t> qa(i_A.size() * 32), tb(i_B.size() * 32);
+        for (size_t i = 0; i < i_A.size(); i++) memcpy(&qa[i * 32], A + (size_t)i_A[i] * 32, 32);
+        for (size_t i = 0; i < i_B.size(); i++) memcpy(&tb[i * 32], B + (size_t)i_B[i] * 32, 32);
+        std::vector<int32_t> idx(i_A.size() * 2), dist(i_A.size() * 2);
+        check(mcorb_knn2(h_, qa.data(), (int)i_A.size(), tb.data(), (int)i_B.size(), idx.data(), dist.data()), "mcorb_knn2");
+        for (size_t a = 0; a < i_A.size(); a++) {
+            const double best_dist_1 = dist[2 * a], best_dist_2 = idx[2 * a + 1] >= 0 ? (double)dist[2 * a + 1] : 1e9;
+            if (best_dist_1 <= TH_LOW && best_dist_1 / best_dist_2 <= max_neighbor_ratio) {
+                const unsigned int idx_B = i_B[idx[2 * a]];
+                size_t k = 0;
+                while (k < i_match_B.size() && i_match_B[k] != idx_B) k++;
+                if (k == i_match_B.size()) {
+                    i_match_B.push_back(idx_B);
+                    i_match_A.push_back(i_A[a]);
+                } else {
+                    const double d = DescriptorDistance(A + (size_t)i_match_A[k] * 32, B + (size_t)idx_B * 32);
+                    BookK++;
+                    if (best_dist_1 < d) i_match_A[k] = i_A[a];
+                }
+            }
+        }
+    }
+
+#ifdef MCORB_WITH_OPENCV
+    // The reference's exact signature (ORBextractor.h:57-59).  cv::KeyPoint and mcorb_keypoint share
+    // their field order, so the keypoints are copied as a block.
+    int operator()(cv::InputArray _image, cv::InputArray _mask, std::vector<cv::KeyPoint> &_keypoints,
+                   cv::OutputArray _descriptors, std::vector<int> &vLappingArea)
+    {
+        (void)_mask;   // "Mask is ignored in the current implementation." (ORBextractor.h:56)
+        if (_image.empty()) return -1;
+        cv::Mat image = _image.getMat();
+        CV_Assert(image.type() == CV_8UC1);
+        std::vector<mcorb_keypoint> k;
+        std::vector<uint8_t> d;
+        const int mono = (*this)(image.data, image.cols, image.rows, (int)image.step, k, d, vLappingArea);
+        static_assert(sizeof(cv::KeyPoint) == sizeof(mcorb_keypoint), "cv::KeyPoint layout");
+        _keypoints.resize(k.size());
+        if (!k.empty()) memcpy((void *)_keypoints.data(), k.data(), k.size() * sizeof(mcorb_keypoint));
+        if (k.empty()) _descriptors.release();
+        else {
+            _descriptors.create((int)k.size(), 32, CV_8U);
+            memcpy(_descriptors.getMat().data, d.data(), d.size());
+        }
+        return mono;
+    }
+    int DescriptorDistance(const cv::Mat &a, const cv::Mat &b) { return mcorb_hamming256(a.data, b.data); }
+#endif
+
+    double max_neighbor_ratio = 0.85;   // ORBextractor.h:90
+
+protected:
+    mcorb_params p_;
+    mcorb_t *h_ = nullptr;
+    std::vector<int> mnFeaturesPerLevel;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+};
+
+// MultiCameraFrame.h:42-57, matchIndex widened from array<int,5> to MCORB_MAX_CAMS entries
+class IntraMatch {
+public:
+    std::array<int, MCORB_MAX_CAMS> matchIndex;
+    bool mono;
+    int n_rays;
+    IntraMatch() : mono(true), n_rays(0) { matchIndex.fill(-1); }
+};
+
+// The extract + intra-rig-match members of MultiCameraFrame for one rig frame.
+class MultiCameraFrontEnd {
+public:
+    MultiCameraFrontEnd(int num_cams, int width, int height, const mcorb_params &p) : num_cams_(num_cams), w_(width), h_(height)
+    {
+        check(mcorb_rig_create(&p, num_cams, width, height, 1, 1, &rig_), "mcorb_rig_create");
+        image_kps.resize(num_cams);
+        image_descriptors.resize(num_cams);
+    }
+    ~MultiCameraFrontEnd() { mcorb_rig_destroy(rig_); }
+
+    // setData (MultiCameraFrame.cpp:95-152): 8-bit gray frames ...
+    void setData(const std::vector<const uint8_t *> &imgs, int stride)
+    {
+        if ((int)imgs.size() != num_cams_) throw std::runtime_error("ERROR:: number of images is wrong");
+        check(mcorb_rig_upload_u8(rig_, 0, imgs.data(), num_cams_, stride), "mcorb_rig_upload_u8");
+    }
+    // ... or the reader's CV_32F [0,1] frames (DatasetReader.cpp:709-712)
+    void setDataF32(const std::vector<const float *> &imgs, int stride_bytes, int channels)
+    {
+        if ((int)imgs.size() != num_cams_) throw std::runtime_error("ERROR:: number of images is wrong");
+        check(mcorb_rig_upload_f32(rig_, 0, imgs.data(), num_cams_, stride_bytes, channels), "mcorb_rig_upload_f32");
+    }
+    // extractFeaturesParallel (MultiCameraFrame.cpp:203-228)
+    void extractFeaturesParallel()
+    {
+        check(mcorb_rig_extract(rig_, 0, num_cams_, 0, 0), "mcorb_rig_extract");
+        const int cap = mcorb_rig_kcap(rig_);
+        for (int c = 0; c < num_cams_; c++) {
+            image_kps[c].resize(cap);
+            image_descriptors[c].resize((size_t)cap * 32);
+            int n = 0, mono = 0;
+            check(mcorb_rig_get_features(rig_, 0, c, image_kps[c].data(), image_descriptors[c].data(), cap, &n, &mono),
+                  "mcorb_rig_get_features");
+            image_kps[c].resize(n);
+            image_descriptors[c].resize((size_t)n * 32);
+        }
+        matched_ = false;
+    }
+    // BruteForceMatch (MultiCameraFrame.cpp:1024-1086), cam1 < cam2 as at every reference call site
+    void BruteForceMatch(int img1_ind, int img2_ind, float dist_thresh, float neigh_ratio,
+                         std::vector<unsigned int> &indices_1, std::vector<unsigned int> &indices_2,
+                         std::vector<mcorb_keypoint> &kps1, std::vector<mcorb_keypoint> &kps2)
+    {
+        ensure_match(dist_thresh, neigh_ratio);
+        const int cap = mcorb_rig_kcap(rig_);
+        indices_1.resize(cap); indices_2.resize(cap);
+        int n = 0;
+        check(mcorb_rig_get_pair_matches(rig_, 0, 0, img1_ind, img2_ind, indices_1.data(), indices_2.data(), cap, &n),
+              "mcorb_rig_get_pair_matches");
+        indices_1.resize(n); indices_2.resize(n);
+        kps1.clear(); kps2.clear();
+        for (int k = 0; k < n; k++) {
+            kps1.push_back(image_kps[img1_ind][indices_1[k]]);   // image_kps_undist == image_kps (RECTIFY=false)
+            kps2.push_back(image_kps[img2_ind][indices_2[k]]);
+        }
+    }
+    // computeIntraMatches(matches, old = false) (MultiCameraFrame.cpp:1100-1288)
+    void computeIntraMatches(std::vector<IntraMatch> &matches, bool old)
+    {
+        if (old) throw std::runtime_error("epipolar gate (old=true) is not part of this path");
+        ensure_match(75, 0.85f);
+        const int cap = mcorb_rig_kcap(rig_) * num_cams_;
+        std::vector<int32_t> tr((size_t)cap * num_cams_);
+        int n = 0;
+        check(mcorb_rig_get_tracks(rig_, 0, 0, tr.data(), cap, &n, &cnt_mergable_matches), "mcorb_rig_get_tracks");
+        matches.clear();
+        matches.resize(n);
+        for (int m = 0; m < n; m++)
+            for (int c = 0; c < num_cams_; c++) matches[m].matchIndex[c] = tr[(size_t)m * num_cams_ + c];
+    }
+
+    int num_cams_;
+    std::vector<std::vector<mcorb_keypoint>> image_kps;
+    std::vector<std::vector<uint8_t>> image_descriptors;   // per camera, n x 32
+    int cnt_mergable_matches = 0;
+
+private:
+    void ensure_match(float thr, float ratio)
+    {
+        if (matched_ && thr == thr_ && ratio == ratio_) return;
+        check(mcorb_rig_match(rig_, 0, 1, thr, ratio), "mcorb_rig_match");
+        matched_ = true; thr_ = thr; ratio_ = ratio;
+    }
+    mcorb_rig *rig_ = nullptr;
+    int w_, h_;
+    bool matched_ = false;
+    float thr_ = 0, ratio_ = 0;
+};
+
+}  // namespace mcorb

@@ -12,6 +12,7 @@
 #include "mcorb_engine.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -350,7 +351,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         slots.push_back(s);
         s->rig = this;
         s->index = si;
-        HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+        if (si > 0 && getenv("MCORB_SHARED_STREAM")) { s->st = slots[0]->st; s->shared_st = true; }
+        else HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&s->st_copy, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&s->st_dma, hipStreamNonBlocking));
         for (auto &e : s->ev) HIPCHK(hipEventCreate(&e));
@@ -422,7 +424,7 @@ Rig::~Rig()
         (void)hipHostFree(s->h_stage);
         (void)hipHostFree(s->h_desc); (void)hipHostFree(s->h_angles);
         for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
-        if (s->st) (void)hipStreamDestroy(s->st);
+        if (s->st && !s->shared_st) (void)hipStreamDestroy(s->st);
         if (s->st_copy) (void)hipStreamDestroy(s->st_copy);
         if (s->st_dma) (void)hipStreamDestroy(s->st_dma);
         delete s;
@@ -533,7 +535,8 @@ void Rig::driver(Slot *sp)
         case Job::MATCH:
             st = enqueue_match(s, j, false);
             if (st == MCORB_OK) {
-                hipError_t e = hipStreamSynchronize(s.st);
+                hipError_t e = hipEventRecord(s.ev[10], s.st);
+                if (e == hipSuccess) e = hipEventSynchronize(s.ev[10]);
                 if (e != hipSuccess) { set_error(hipGetErrorString(e)); st = MCORB_E_HIP; }
             }
             if (st == MCORB_OK) st = finish_match(s, j);
@@ -651,7 +654,8 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
         HIPCHK(hipMemcpyAsync(s.h_angles, s.d_angles, (size_t)nimg * geom.kcap * sizeof(float), hipMemcpyDeviceToHost, s.st_dma));
     if (then_match) TRY(enqueue_match(s, j, true));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(s.st));
+    HIPCHK(hipEventRecord(s.ev[10], s.st));
+    HIPCHK(hipEventSynchronize(s.ev[10]));   // event, not stream: the compute stream may be shared between slots
     HIPCHK(hipStreamSynchronize(s.st_dma));
     if (params.orientation)
         for (int m = 0; m < nimg; m++)

@@ -81,6 +81,7 @@ class Rig;
 struct Slot {
     Rig *rig = nullptr;
     int index = 0;
+    bool shared_st = false;
     hipStream_t st = nullptr, st_copy = nullptr, st_dma = nullptr;   // compute; PCIe-bound compaction kernel; D2H copies only
     hipEvent_t ev[12] = {};  // 0 start, 1 pyramid done, 2 FAST done, 3 compact done, 4 blur done, 5/6 describe(+D2H), 7 knn2 start, 8 knn2 done, 9 finalize done
     // device

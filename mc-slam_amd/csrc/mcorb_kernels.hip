@@ -17,6 +17,15 @@ namespace mcorb {
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// XCD-aware work index: workgroups b and b+8 share an XCD (and its L2) under the observed round-robin
+// placement, so give each XCD one contiguous eighth of the work items -- spatial neighbours (cells or
+// tiles that re-read the same 64-B lines for their halos) then hit in the same L2.  Bijective for any n;
+// placement only changes speed, never results.
+__device__ __forceinline__ int xcd_remap(int b, int n)
+{
+    const int q = n >> 3, r = n & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
 __device__ __forceinline__ int reflect101(int p, int len)
 {
     // cv::borderInterpolate(BORDER_REFLECT_101); |overshoot| < len here
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     uint16_t *work = reinterpret_cast<uint16_t *>(lds + 2 * tileBytes);
 
     const int lane = threadIdx.x;
-    const int cell = blockIdx.x, img = blockIdx.y;
+    const int cell = xcd_remap(blockIdx.x, gridDim.x), img = blockIdx.y;
     int level = 0;
 #pragma unroll 1
     for (int l = 1; l < g.nlevels; l++)
@@ -535,12 +544,13 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     __shared__ __attribute__((aligned(16))) uint2 hb[(TH + 6) * (TW / 4)];   // 4 x u16 per entry
     const int tid = threadIdx.x;
     const int img = blockIdx.y;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
     int level = 0;
 #pragma unroll 1
     for (int l = 1; l < g.nlevels; l++)
-        if ((int)blockIdx.x >= g.lv[l].tile0) level = l;
+        if (tile >= g.lv[l].tile0) level = l;
     const LevelGeom &L = g.lv[level];
-    const int t = blockIdx.x - L.tile0;
+    const int t = tile - L.tile0;
     const int ty = t / L.tilesX, tx = t - ty * L.tilesX;
     const int x0 = tx * TW, y0 = ty * TH;
     const uint8_t *plane = pyr + (size_t)img * g.imgBytes + L.off;
