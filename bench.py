@@ -85,8 +85,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=32, help="rig frames per rank per step")
-    ap.add_argument("--slots", type=int, default=4, help="sub-batches in flight per rank")
+    ap.add_argument("--frames", type=int, default=48, help="rig frames per rank per step")
+    ap.add_argument("--slots", type=int, default=6, help="sub-batches in flight per rank")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); 'gloo' only to rehearse N>1 on a 1-GPU box")
@@ -167,31 +167,54 @@ def main():
                 dist.all_gather_into_tensor(all_cnt, local_cnt)
             counts = all_cnt.cpu().numpy()                      # syncs the collective
             for s in range(S):                                  # this rank's frames, split over the slots
-                part = sets[s * fps:(s + 1) * fps]
-                rig.match_external(all_desc.data_ptr(), counts, part, slot=s)
+                rig.match_external_submit(all_desc.data_ptr(), counts, sets[s * fps:(s + 1) * fps], slot=s)
+            for s in range(S):
+                rig.match_wait(slot=s)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
     # per-kernel durations, accumulated from the HIP events the engine records on each slot's stream
-    ksum = {"k_resize": 0.0, "k_fast_cells": 0.0, "k_compact": 0.0, "blur+describe": 0.0, "k_knn2": 0.0,
-            "select_host": 0.0}
+    ksum = {"k_resize": 0.0, "k_fast_cells": 0.0, "k_blur": 0.0, "k_describe": 0.0, "k_knn2": 0.0,
+            "side:k_compact": 0.0, "select_host": 0.0}
+
+    def account(s):
+        t = rig.timing(slot=s)
+        ksum["k_resize"] += t["pyramid_us"]
+        ksum["k_fast_cells"] += t["fast_us"]
+        ksum["side:k_compact"] += t["compact_us"]
+        ksum["k_blur"] += t["blur_us"]
+        ksum["k_describe"] += t["describe_us"]
+        ksum["k_knn2"] += t["knn2_us"]
+        ksum["select_host"] += t["select_us"]
+
+    def run_steps(nsteps, timed):
+        """nsteps steps = nsteps*S sub-batch jobs.  N == 1: rolling submission, S jobs always in flight (a slot is
+        resubmitted as soon as its previous job is collected), so step boundaries do not drain the pipeline."""
+        if N > 1:
+            for _ in range(nsteps):
+                step()
+                if timed:
+                    for s in range(S):
+                        account(s)
+            return
+        jobs = nsteps * S
+        for s in range(min(S, jobs)):
+            rig.process_submit(fps, slot=s)
+        for j in range(jobs):
+            s = j % S
+            rig.process_wait(slot=s)
+            if timed:
+                account(s)
+            if j + S < jobs:
+                rig.process_submit(fps, slot=s)
+
+    run_steps(args.warmup, False)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        for s in range(S):
-            t = rig.timing(slot=s)
-            ksum["k_resize"] += t["pyramid_us"]
-            ksum["k_fast_cells"] += t["fast_us"]
-            ksum["k_compact"] += t["compact_us"]
-            ksum["blur+describe"] += t["phase_b_us"]
-            ksum["k_knn2"] += t["knn2_us"]
-            ksum["select_host"] += t["select_us"]
+    run_steps(args.steps, True)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
@@ -225,7 +248,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if measured
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(dominant, {}).get("bytes_per_launch")
+            traffic = int(json.load(open(tpath)).get(dominant, {}).get("bytes_per_image") * nimg_launch)
         except Exception:
             traffic = None
     out = {

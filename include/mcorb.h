@@ -144,9 +144,9 @@ int mcorb_rig_get_candidates(mcorb_rig *r, int slot, int m, int level, uint32_t 
 /* timing of the last completed job of a slot, microseconds between HIP events
  * recorded on the slot's stream around the launches:
  * [0] pyramid+FAST+compaction, [1] host selection wall time, [2] blur + describe(+D2H),
- * [3] k-NN + finalize, [4] pyramid launches, [5] FAST kernel alone, [6] compaction kernel,
- * [7] k-NN kernel alone */
-int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[8]);
+ * [3] k-NN + finalize, [4] pyramid launches, [5] FAST kernel alone, [6] compaction kernel (side stream),
+ * [7] k-NN kernel alone, [8] blur kernel, [9] describe kernel */
+int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[10]);
 
 /* multi-GPU plumbing (one process per GPU; the collective itself is the
  * caller's, e.g. an RCCL all-gather over torch.distributed).
@@ -163,6 +163,9 @@ int mcorb_rig_export_descriptors(mcorb_rig *r, int slot, void *dst_dev, int32_t 
  * mcorb_rig_get_pair_matches / _get_pair_knn2 / _get_tracks as for mcorb_rig_match. */
 int mcorb_rig_match_external(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts, int ntotal,
                              const int32_t *sets, int nframes, float dist_thresh, float ratio);
+/* asynchronous form: counts/sets must stay valid until mcorb_rig_match_wait(r, slot) returns */
+int mcorb_rig_match_external_submit(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts, int ntotal,
+                                    const int32_t *sets, int nframes, float dist_thresh, float ratio);
 
 /* ------------------------------------------------------------------------- */
 /* Single-camera extractor: ORBextractor (ORBextractor.h:43-116)              */

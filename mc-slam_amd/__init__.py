@@ -166,10 +166,10 @@ class Rig:
         return ((p >> 8) & 0xfff).astype(np.int32), (p >> 20).astype(np.int32), (p & 0xff).astype(np.int32)
 
     def timing(self, slot=0):
-        t = (C.c_float * 8)()
+        t = (C.c_float * 10)()
         _lib.check(self.L.mcorb_rig_last_timing(self.h_rig, slot, t))
         return dict(phase_a_us=t[0], select_us=t[1], phase_b_us=t[2], match_us=t[3], pyramid_us=t[4],
-                    fast_us=t[5], compact_us=t[6], knn2_us=t[7])
+                    fast_us=t[5], compact_us=t[6], knn2_us=t[7], blur_us=t[8], describe_us=t[9])
 
     # -- multi-GPU plumbing ---------------------------------------------------
     def export_descriptors(self, dst_dev_ptr, nimg, slot=0):
@@ -178,10 +178,19 @@ class Rig:
         return counts
 
     def match_external(self, desc_dev_ptr, counts, sets, slot=0, dist_thresh=75.0, ratio=0.85):
+        self.match_external_submit(desc_dev_ptr, counts, sets, slot, dist_thresh, ratio)
+        self.match_wait(slot)
+
+    def match_external_submit(self, desc_dev_ptr, counts, sets, slot=0, dist_thresh=75.0, ratio=0.85):
         counts = np.ascontiguousarray(counts, np.int32)
         sets = np.ascontiguousarray(sets, np.int32).reshape(-1, self.ncams)
-        _lib.check(self.L.mcorb_rig_match_external(self.h_rig, slot, desc_dev_ptr, counts.ctypes.data, len(counts),
-                                                   sets.ctypes.data, len(sets), dist_thresh, ratio))
+        self._keep = getattr(self, "_keep", {})
+        self._keep[slot] = (counts, sets)          # must outlive the asynchronous job
+        _lib.check(self.L.mcorb_rig_match_external_submit(self.h_rig, slot, desc_dev_ptr, counts.ctypes.data, len(counts),
+                                                          sets.ctypes.data, len(sets), dist_thresh, ratio))
+
+    def match_wait(self, slot=0):
+        _lib.check(self.L.mcorb_rig_match_wait(self.h_rig, slot))
 
 
 class ORBextractor:

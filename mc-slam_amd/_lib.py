@@ -69,6 +69,7 @@ SIGNATURES = {
     "mcorb_rig_stream": (_vp, [_vp, _i]),
     "mcorb_rig_export_descriptors": (_i, [_vp, _i, _vp, _vp, _i]),
     "mcorb_rig_match_external": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _f, _f]),
+    "mcorb_rig_match_external_submit": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _f, _f]),
     "mcorb_create": (_i, [C.POINTER(Params), _i, _i, C.POINTER(_vp)]),
     "mcorb_destroy": (None, [_vp]),
     "mcorb_extract": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _ip, _ip]),

@@ -292,11 +292,11 @@ int mcorb_rig_get_candidates(mcorb_rig *r, int slot, int m, int level, uint32_t 
     return MCORB_OK;
 }
 
-int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[8])
+int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[10])
 {
     Slot *s = get_slot(r, slot);
     if (!s) return MCORB_E_STATE;
-    for (int i = 0; i < 8; i++) us[i] = s->timing[i];
+    for (int i = 0; i < 10; i++) us[i] = s->timing[i];
     return MCORB_OK;
 }
 
@@ -312,14 +312,20 @@ void *mcorb_rig_stream(mcorb_rig *r, int slot)
     return (void *)r->rig.slots[slot]->st;
 }
 
-int mcorb_rig_match_external(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts, int ntotal,
-                             const int32_t *sets, int nframes, float dist_thresh, float ratio)
+int mcorb_rig_match_external_submit(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts, int ntotal,
+                                    const int32_t *sets, int nframes, float dist_thresh, float ratio)
 {
     if (!r || !desc_dev || !counts || !sets) { set_error("null argument"); return MCORB_E_ARG; }
     Job j;
     j.kind = Job::MATCH; j.nframes = nframes; j.dist_thresh = dist_thresh; j.ratio = ratio;
     j.ext_desc = desc_dev; j.ext_counts = counts; j.ext_total = ntotal; j.ext_sets = sets;
-    const int st = r->rig.submit(slot, j);
+    return r->rig.submit(slot, j);
+}
+
+int mcorb_rig_match_external(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts, int ntotal,
+                             const int32_t *sets, int nframes, float dist_thresh, float ratio)
+{
+    const int st = mcorb_rig_match_external_submit(r, slot, desc_dev, counts, ntotal, sets, nframes, dist_thresh, ratio);
     return st != MCORB_OK ? st : r->rig.wait(slot);
 }
 

@@ -315,7 +315,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         selp[l] = make_select_params(kMinBorder, geom.lv[l].maxBorderX, kMinBorder, geom.lv[l].maxBorderY, tab.quota[l],
                                      geom.lv[l].wCell, geom.lv[l].hCell);
     if (taps.empty()) taps.push_back(ResizeTap{0, 0, 0, 0});
-    // LDS source window of one resize workgroup (256 x 4 outputs): widest column span / tallest row span per level
+    // LDS source window of one resize workgroup (256 x kResizeTileH outputs): widest column span / tallest row span per level
     for (int l = 1; l < geom.nlevels; l++) {
         const LevelGeom &D = geom.lv[l];
         int maxc = 4, maxr = 2;
@@ -324,8 +324,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
             const int a = taps[D.xtab + bx0].s0 & ~3, b = taps[D.xtab + bx1].s1;
             maxc = std::max(maxc, ((b - a) / 4 + 1) * 4);
         }
-        for (int by0 = 0; by0 < D.h; by0 += 4) {
-            const int by1 = std::min(by0 + 3, D.h - 1);
+        for (int by0 = 0; by0 < D.h; by0 += kResizeTileH) {
+            const int by1 = std::min(by0 + kResizeTileH - 1, D.h - 1);
             maxr = std::max(maxr, (int)taps[D.ytab + by1].s1 - (int)taps[D.ytab + by0].s0 + 1);
         }
         resize_win[2 * l] = maxc;
@@ -667,6 +667,8 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     (void)hipEventElapsedTime(&c, s.ev[5], s.ev[6]);
     s.timing[0] = a * 1000.f;
     s.timing[2] = (b + c) * 1000.f;
+    s.timing[8] = b * 1000.f;   // k_blur
+    s.timing[9] = c * 1000.f;   // k_describe
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[1]); s.timing[4] = t * 1000.f;   // pyramid launches
     (void)hipEventElapsedTime(&t, s.ev[1], s.ev[2]); s.timing[5] = t * 1000.f;   // k_fast_cells
     (void)hipEventElapsedTime(&t, s.ev[2], s.ev[3]); s.timing[6] = t * 1000.f;   // k_compact

@@ -116,7 +116,7 @@ struct Slot {
     std::vector<std::vector<uint32_t>> m_idx1, m_idx2;   // per pair
     std::vector<std::vector<int32_t>> tracks;            // per frame, ncams ints per track
     std::vector<int> mergeable;
-    float timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float timing[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<int> match_sets, match_counts;   // per (frame, cam) of the last match: set index, descriptor count
     bool match_external = false;
     // driver thread

@@ -73,6 +73,8 @@ __global__ __launch_bounds__(256) void k_stage_f32(const float *__restrict__ src
 // ~1.2 x 256 columns) is staged in LDS with aligned dword loads; each thread
 // then produces 4 consecutive output pixels of one row -> one dword store.
 // ---------------------------------------------------------------------------
+constexpr int kResizeRows = kResizeTileH;   // output rows per workgroup (4 per thread): amortises the window fill + barrier
+
 __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom g, int level,
                                                 const ResizeTap *__restrict__ tabs, int srcPitch, int srcRows)
 {
@@ -82,8 +84,8 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
     const int img = blockIdx.z;
     uint8_t *base = pyr + (size_t)img * g.imgBytes;
     const int tid = threadIdx.x;
-    const int bx0 = blockIdx.x * 256, by0 = blockIdx.y * 4;
-    const int bx1 = min(bx0 + 255, D.w - 1), by1 = min(by0 + 3, D.h - 1);
+    const int bx0 = blockIdx.x * 256, by0 = blockIdx.y * kResizeRows;
+    const int bx1 = min(bx0 + 255, D.w - 1), by1 = min(by0 + kResizeRows - 1, D.h - 1);
     // source window of this workgroup (tables are monotone)
     const int sx0 = tabs[D.xtab + bx0].s0 & ~3, sx1 = tabs[D.xtab + bx1].s1;
     const int sy0 = tabs[D.ytab + by0].s0, sy1 = tabs[D.ytab + by1].s1;
@@ -92,35 +94,46 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
         const uint8_t *sp = base + S.off + (size_t)sy0 * S.pitch + sx0;
         uint32_t *w32 = reinterpret_cast<uint32_t *>(win);
         const int pd = srcPitch >> 2;
+        const float rcp_pd = 1.0f / (float)pd;
         for (int i = tid; i < nr * pd; i += 256) {
-            const int r = i / pd, d = i - r * pd;
+            const int r = (int)(((float)i + 0.5f) * rcp_pd), d = i - r * pd;
             if (d < nd) w32[i] = *reinterpret_cast<const uint32_t *>(sp + (size_t)r * S.pitch + 4 * d);
         }
     }
     __syncthreads();
     const int dx4 = bx0 + (tid & 63) * 4;
-    const int dy = by0 + (tid >> 6);
-    if (dy >= D.h || dx4 >= D.w) return;
-    const ResizeTap ty = tabs[D.ytab + dy];
-    const uint8_t *S0 = win + (ty.s0 - sy0) * srcPitch - sx0;
-    const uint8_t *S1 = win + (ty.s1 - sy0) * srcPitch - sx0;
-    const int b0 = ty.c0, b1 = ty.c1;
+    if (dx4 >= D.w) return;
     const uint4 t01 = *reinterpret_cast<const uint4 *>(tabs + D.xtab + dx4);       // 4 taps, 8 bytes each
     const uint4 t23 = *reinterpret_cast<const uint4 *>(tabs + D.xtab + dx4 + 2);
     const uint32_t tw[8] = {t01.x, t01.y, t01.z, t01.w, t23.x, t23.y, t23.z, t23.w};
-    uint32_t out = 0;
+    int s0[4], s1[4], a0[4], a1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int s0 = tw[2 * k] & 0xffff, s1 = tw[2 * k] >> 16;
-        const int a0 = (int)(short)(tw[2 * k + 1] & 0xffff), a1 = (int)(short)(tw[2 * k + 1] >> 16);
         const bool ok = dx4 + k < D.w;   // padded taps point at column 0 of the image, which may be outside the window
-        const int R0 = ok ? S0[s0] * a0 + S0[s1] * a1 : 0;
-        const int R1 = ok ? S1[s0] * a0 + S1[s1] * a1 : 0;
-        const int v = (((b0 * (R0 >> 4)) >> 16) + ((b1 * (R1 >> 4)) >> 16) + 2) >> 2;
-        out |= (uint32_t)(v & 0xff) << (8 * k);
+        s0[k] = ok ? (int)(tw[2 * k] & 0xffff) - sx0 : 0;
+        s1[k] = ok ? (int)(tw[2 * k] >> 16) - sx0 : 0;
+        a0[k] = ok ? (int)(short)(tw[2 * k + 1] & 0xffff) : 0;
+        a1[k] = ok ? (int)(short)(tw[2 * k + 1] >> 16) : 0;
     }
-    if (dx4 + 4 > D.w) out &= 0xffffffffu >> (8 * (dx4 + 4 - D.w));   // keep the row padding zero
-    *reinterpret_cast<uint32_t *>(base + D.off + (size_t)dy * D.pitch + dx4) = out;
+    const uint32_t mask = dx4 + 4 > D.w ? 0xffffffffu >> (8 * (dx4 + 4 - D.w)) : 0xffffffffu;   // keep the row padding zero
+#pragma unroll
+    for (int rr = 0; rr < kResizeRows / 4; rr++) {
+        const int dy = by0 + (tid >> 6) + 4 * rr;
+        if (dy >= D.h) break;
+        const ResizeTap ty = tabs[D.ytab + dy];
+        const uint8_t *S0 = win + (ty.s0 - sy0) * srcPitch;
+        const uint8_t *S1 = win + (ty.s1 - sy0) * srcPitch;
+        const int b0 = ty.c0, b1 = ty.c1;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int R0 = S0[s0[k]] * a0[k] + S0[s1[k]] * a1[k];
+            const int R1 = S1[s0[k]] * a0[k] + S1[s1[k]] * a1[k];
+            const int v = (((b0 * (R0 >> 4)) >> 16) + ((b1 * (R1 >> 4)) >> 16) + 2) >> 2;
+            out |= (uint32_t)(v & 0xff) << (8 * k);
+        }
+        *reinterpret_cast<uint32_t *>(base + D.off + (size_t)dy * D.pitch + dx4) = out & mask;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -638,10 +651,71 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
     return a;
 }
 
-__global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
-                                                  Geom g, const uint32_t *__restrict__ sel,
-                                                  const int *__restrict__ nsel, int orientation,
-                                                  uint8_t *__restrict__ desc, float *__restrict__ angles)
+constexpr int kDescPerWave = 4;   // keypoints per wave
+constexpr int kPatchRows = 27, kPatchDw = 8;   // unrotated taps lie within +-13 px: 27 rows x 32 aligned bytes
+
+// Reference behaviour (angle = 0): the 27x27 neighbourhood of each keypoint is staged in LDS with
+// row-coalesced dword loads, then the 512 taps are LDS byte reads.  (Gathering the taps straight
+// from global memory is bound by the texture addresser at ~1 lane/clk for divergent byte loads.)
+__global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ blur, Geom g,
+                                                  const uint32_t *__restrict__ sel, const int *__restrict__ nsel,
+                                                  uint8_t *__restrict__ desc)
+{
+    __shared__ uint32_t patch[4][kDescPerWave][kPatchRows * kPatchDw];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int img = blockIdx.y;
+    const int k0 = (blockIdx.x * 4 + wave) * kDescPerWave;
+    const int n = nsel[img];
+    if (k0 >= n) return;
+
+    int shift[kDescPerWave];
+#pragma unroll
+    for (int u = 0; u < kDescPerWave; u++) {
+        const int k = k0 + u < n ? k0 + u : n - 1;   // tail keypoints are recomputed, never stored
+        const uint32_t s = sel[(size_t)img * g.kcap + k];
+        const int level = (int)(s >> 28), ky = (int)((s >> 14) & 0x3fffu), kx = (int)(s & 0x3fffu);
+        const LevelGeom &L = g.lv[level];
+        const int bx = (kx - 13) & ~3;               // keypoints sit >= 19 px from every edge: window is in range
+        shift[u] = kx - bx;                           // 13..16
+        const uint8_t *src = blur + (size_t)img * g.imgBytes + L.off + (size_t)(ky - 13) * L.pitch + bx;
+#pragma unroll
+        for (int t = 0; t < (kPatchRows * kPatchDw + 63) / 64; t++) {
+            const int i = t * 64 + lane;
+            if (i < kPatchRows * kPatchDw)
+                patch[wave][u][i] = *reinterpret_cast<const uint32_t *>(src + (size_t)(i >> 3) * L.pitch + 4 * (i & 7));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // each wave only reads the patches it wrote itself
+
+    // this lane's four test pairs (pairs lane, 64+lane, 128+lane, 192+lane) as LDS byte offsets
+    int o0[4], o1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = (j * 64 + lane) * 4;
+        o0[j] = (c_pattern[p + 1] + 13) * (kPatchDw * 4) + c_pattern[p];
+        o1[j] = (c_pattern[p + 3] + 13) * (kPatchDw * 4) + c_pattern[p + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < kDescPerWave; u++) {
+        const uint8_t *c = reinterpret_cast<const uint8_t *>(patch[wave][u]) + shift[u];
+        unsigned long long bits[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) bits[j] = __ballot(c[o0[j]] < c[o1[j]]);
+        if (lane < 4 && k0 + u < n) {
+            const unsigned long long b = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+            reinterpret_cast<unsigned long long *>(desc + ((size_t)img * g.kcap + k0 + u) * 32)[lane] = b;
+        }
+    }
+}
+
+// IC_Angle enabled (non-reference mode): orientation from the un-blurred level, rotated taps
+// (up to +-19 px) gathered from global memory.
+__global__ __launch_bounds__(256) void k_describe_oriented(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
+                                                           Geom g, const uint32_t *__restrict__ sel,
+                                                           const int *__restrict__ nsel, uint8_t *__restrict__ desc,
+                                                           float *__restrict__ angles)
 {
     const int lane = lane_id();
     const int img = blockIdx.y;
@@ -653,51 +727,44 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ py
     const int pitch = L.pitch;
     const size_t coff = (size_t)img * g.imgBytes + L.off + (size_t)ky * pitch + kx;
 
-    float ca = 1.f, sa = 0.f;
-    if (orientation) {
-        // IC_Angle (ORBextractor.cpp:75-102) on the un-blurred level; lanes share the 31 rows
-        const uint8_t *c = pyr + coff;
-        int m01 = 0, m10 = 0;
-        if (lane < 31) {
-            const int u = lane - 15;
-            m10 = u * c[u];
-        }
-        for (int v = 1; v <= 15; v++) {
-            const int d = c_umax[v];
-            if (lane <= 2 * d) {
-                const int u = lane - d;
-                const int vp = c[u + v * pitch], vm = c[u - v * pitch];
-                m01 += v * (vp - vm);
-                m10 += u * (vp + vm);
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            m01 += __shfl_xor(m01, o);
-            m10 += __shfl_xor(m10, o);
-        }
-        const float ang = fast_atan2_deg((float)m01, (float)m10);
-        if (lane == 0) angles[(size_t)img * g.kcap + k] = ang;
-        const float rad = __fmul_rn(ang, (float)(3.14159265358979323846 / 180.f));
-        ca = cosf(rad);
-        sa = sinf(rad);
+    // IC_Angle (ORBextractor.cpp:75-102) on the un-blurred level; lanes share the 31 rows
+    const uint8_t *c = pyr + coff;
+    int m01 = 0, m10 = 0;
+    if (lane < 31) {
+        const int uu = lane - 15;
+        m10 = uu * c[uu];
     }
+    for (int v = 1; v <= 15; v++) {
+        const int d = c_umax[v];
+        if (lane <= 2 * d) {
+            const int uu = lane - d;
+            const int vp = c[uu + v * pitch], vm = c[uu - v * pitch];
+            m01 += v * (vp - vm);
+            m10 += uu * (vp + vm);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        m01 += __shfl_xor(m01, o);
+        m10 += __shfl_xor(m10, o);
+    }
+    const float ang = fast_atan2_deg((float)m01, (float)m10);
+    if (lane == 0) angles[(size_t)img * g.kcap + k] = ang;
+    const float rad = __fmul_rn(ang, (float)(3.14159265358979323846 / 180.f));
+    const float ca = cosf(rad), sa = sinf(rad);
 
-    const uint8_t *c = blur + coff;
+    const uint8_t *cb = blur + coff;
     unsigned long long bits[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int p = (j * 64 + lane) * 4;
-        const int x0 = c_pattern[p], y0 = c_pattern[p + 1], x1 = c_pattern[p + 2], y1 = c_pattern[p + 3];
-        int ox0 = x0, oy0 = y0, ox1 = x1, oy1 = y1;
-        if (orientation) {
-            // cvRound(x*b + y*a), cvRound(x*a - y*b) with a = cos, b = sin (:117-118)
-            oy0 = __float2int_rn(__fadd_rn(__fmul_rn((float)x0, sa), __fmul_rn((float)y0, ca)));
-            ox0 = __float2int_rn(__fsub_rn(__fmul_rn((float)x0, ca), __fmul_rn((float)y0, sa)));
-            oy1 = __float2int_rn(__fadd_rn(__fmul_rn((float)x1, sa), __fmul_rn((float)y1, ca)));
-            ox1 = __float2int_rn(__fsub_rn(__fmul_rn((float)x1, ca), __fmul_rn((float)y1, sa)));
-        }
-        const int t0 = c[oy0 * pitch + ox0], t1 = c[oy1 * pitch + ox1];
+        const float x0 = (float)c_pattern[p], y0 = (float)c_pattern[p + 1], x1 = (float)c_pattern[p + 2], y1 = (float)c_pattern[p + 3];
+        // cvRound(x*b + y*a), cvRound(x*a - y*b) with a = cos, b = sin (:117-118)
+        const int oy0 = __float2int_rn(__fadd_rn(__fmul_rn(x0, sa), __fmul_rn(y0, ca)));
+        const int ox0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sa)));
+        const int oy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
+        const int ox1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
+        const int t0 = cb[oy0 * pitch + ox0], t1 = cb[oy1 * pitch + ox1];
         bits[j] = __ballot(t0 < t1);
     }
     if (lane < 4) {
@@ -822,7 +889,7 @@ void launch_stage_f32(hipStream_t st, const float *src, int w, int h, int pitch_
 void launch_pyramid(hipStream_t st, uint8_t *pyr, const Geom &g, const ResizeTap *tabs, const int *win, int nimg)
 {
     for (int l = 1; l < g.nlevels; l++) {
-        dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + 3) / 4, nimg);
+        dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + kResizeRows - 1) / kResizeRows, nimg);
         const int srcPitch = win[2 * l], srcRows = win[2 * l + 1];   // LDS window, sized on the host from the tables
         hipLaunchKernelGGL(k_resize, grid, dim3(256), (size_t)srcPitch * srcRows, st, pyr, g, l, tabs, srcPitch, srcRows);
     }
@@ -865,8 +932,13 @@ void launch_blur(hipStream_t st, const uint8_t *pyr, uint8_t *blur, const Geom &
 void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, const Geom &g, const uint32_t *sel,
                      const int *nsel, int orientation, uint8_t *desc, float *angles, int nimg)
 {
-    dim3 grid((g.kcap + 3) / 4, nimg);
-    hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, pyr, blur, g, sel, nsel, orientation, desc, angles);
+    if (orientation) {
+        dim3 grid((g.kcap + 3) / 4, nimg);
+        hipLaunchKernelGGL(k_describe_oriented, grid, dim3(256), 0, st, pyr, blur, g, sel, nsel, desc, angles);
+    } else {
+        dim3 grid((g.kcap + 4 * kDescPerWave - 1) / (4 * kDescPerWave), nimg);
+        hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, blur, g, sel, nsel, desc);
+    }
 }
 
 void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const int2 *pairs, int npairs, int kcap,

@@ -40,7 +40,7 @@ def test_cpp_adapter_matches_oracle():
     C, W, H, N, frame = 3, 640, 480, 1000, 1
     out = subprocess.run([EXE, str(C), str(W), str(H), str(N), str(frame)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+    lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines() if " " in l)
     imgs = [mcorb.synth_rig_frame(frame, C, c, W, H) for c in range(C)]
     ora = [O.OracleExtractor(N)(im) for im in imgs]
     F0 = 1469598103934665603
