@@ -85,12 +85,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=48, help="rig frames per rank per step")
-    ap.add_argument("--slots", type=int, default=6, help="sub-batches in flight per rank")
+    ap.add_argument("--frames", type=int, default=None, help="rig frames per rank per step (default 48; 72 on the N>1 path)")
+    ap.add_argument("--slots", type=int, default=None, help="buffer sets in flight per rank (default 6; 9 on the N>1 path)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); 'gloo' only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses device 0")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: take the N>1 code path (export -> RCCL all-gather -> external match) even at N=1")
     args = ap.parse_args()
 
     import torch
@@ -107,17 +109,26 @@ def main():
     torch.cuda.set_device(local)
     dist = None
     gloo = args.dist_backend == "gloo"
-    if N > 1:
+    DIST = N > 1 or args.force_dist     # use the sharded path (export -> all-gather -> external match)
+    if DIST:
         import torch.distributed as dist
+        if args.force_dist and "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29555")
         if gloo:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
-    F, S = args.frames, max(1, min(args.slots, args.frames))
-    fps = F // S                       # rig frames per slot
-    if fps * S != F:
-        raise SystemExit("--frames must be a multiple of --slots")
+    F = args.frames if args.frames else (72 if DIST else 48)
+    S = args.slots if args.slots else (9 if DIST else 6)
+    S = max(1, min(S, F))
+    G = 3 if DIST else 1               # slot groups: with N > 1 two groups extract steps k+1, k+2 while the third matches step k
+    if DIST and S % G:
+        S += G - S % G
+    SG = S // G                        # slots per group
+    fps = F // SG                      # rig frames per slot job
+    if fps * SG != F:
+        raise SystemExit("--frames must be a multiple of the slots per group (%d)" % SG)
     rig = mcorb.Rig(NCAMS, W, H, max_frames=fps, nslots=S, nfeatures=NFEAT, device_id=local)
     kcap = rig.kcap
     total_frames = F * N
@@ -125,51 +136,51 @@ def main():
     # ---- inputs: synthetic rig frames, staged into HBM before the timed region ----
     from importlib import import_module
     shard = import_module("mc-slam_amd.sharding")
-    if N == 1:
+    if not DIST:
         mine = [(f, c) for f in range(F) for c in range(NCAMS)]
     else:
         mine = shard.images_of_rank(rank, N, NCAMS, total_frames)
     assert len(mine) == F * NCAMS, (len(mine), F * NCAMS)
     per_slot = fps * NCAMS
     for s in range(S):
-        imgs = [mcorb.synth_rig_frame(f, NCAMS, c, W, H) for (f, c) in mine[s * per_slot:(s + 1) * per_slot]]
+        i = s % SG
+        imgs = [mcorb.synth_rig_frame(f, NCAMS, c, W, H) for (f, c) in mine[i * per_slot:(i + 1) * per_slot]]
         rig.upload(imgs, slot=s)
 
-    if N > 1:
-        local_desc = torch.zeros((F * NCAMS, kcap, 32), dtype=torch.uint8, device="cuda")
-        all_desc = torch.zeros((N * F * NCAMS, kcap, 32), dtype=torch.uint8, device="cuda")
-        local_cnt = torch.zeros(F * NCAMS, dtype=torch.int32, device="cuda")
-        all_cnt = torch.zeros(N * F * NCAMS, dtype=torch.int32, device="cuda")
+    if DIST:
+        local_desc = [torch.zeros((F * NCAMS, kcap, 32), dtype=torch.uint8, device="cuda") for _ in range(G)]
+        all_desc = [torch.zeros((N * F * NCAMS, kcap, 32), dtype=torch.uint8, device="cuda") for _ in range(G)]
+        local_cnt = [torch.zeros(F * NCAMS, dtype=torch.int32, device="cuda") for _ in range(G)]
+        all_cnt = [torch.zeros(N * F * NCAMS, dtype=torch.int32, device="cuda") for _ in range(G)]
         my_frames, sets = shard.match_sets(rank, N, NCAMS, total_frames)   # gathered set index of (f, c)
         assert len(my_frames) == F
 
-    def step():
-        if N == 1:
-            for s in range(S):
-                rig.process_submit(fps, slot=s)
-            for s in range(S):
-                rig.process_wait(slot=s)
+    def extract_submit(g):
+        for i in range(SG):
+            rig.extract_submit(per_slot, slot=g * SG + i)
+
+    def exchange_and_match(g):
+        cnt_host = np.zeros(F * NCAMS, np.int32)
+        for i in range(SG):
+            s = g * SG + i
+            rig.extract_wait(slot=s)
+            cnt_host[i * per_slot:(i + 1) * per_slot] = rig.export_descriptors(local_desc[g][i * per_slot].data_ptr(),
+                                                                               per_slot, slot=s)
+        local_cnt[g].copy_(torch.from_numpy(cnt_host))
+        if gloo:                                                # rehearsal path only
+            hd, hc = torch.zeros(all_desc[g].shape, dtype=torch.uint8), torch.zeros(all_cnt[g].shape, dtype=torch.int32)
+            dist.all_gather_into_tensor(hd, local_desc[g].cpu())
+            dist.all_gather_into_tensor(hc, local_cnt[g].cpu())
+            all_desc[g].copy_(hd)
+            all_cnt[g].copy_(hc)
         else:
-            for s in range(S):
-                rig.extract_submit(per_slot, slot=s)
-            for s in range(S):
-                rig.extract_wait(slot=s)
-                cnt = rig.export_descriptors(local_desc[s * per_slot].data_ptr(), per_slot, slot=s)
-                local_cnt[s * per_slot:(s + 1) * per_slot] = torch.from_numpy(cnt).cuda()
-            if gloo:                                            # rehearsal path only
-                hd, hc = torch.zeros(all_desc.shape, dtype=torch.uint8), torch.zeros(all_cnt.shape, dtype=torch.int32)
-                dist.all_gather_into_tensor(hd, local_desc.cpu())
-                dist.all_gather_into_tensor(hc, local_cnt.cpu())
-                all_desc.copy_(hd)
-                all_cnt.copy_(hc)
-            else:
-                dist.all_gather_into_tensor(all_desc, local_desc)   # the exchange step (RCCL over xGMI)
-                dist.all_gather_into_tensor(all_cnt, local_cnt)
-            counts = all_cnt.cpu().numpy()                      # syncs the collective
-            for s in range(S):                                  # this rank's frames, split over the slots
-                rig.match_external_submit(all_desc.data_ptr(), counts, sets[s * fps:(s + 1) * fps], slot=s)
-            for s in range(S):
-                rig.match_wait(slot=s)
+            dist.all_gather_into_tensor(all_desc[g], local_desc[g])   # the exchange step (RCCL over xGMI)
+            dist.all_gather_into_tensor(all_cnt[g], local_cnt[g])
+        counts = all_cnt[g].cpu().numpy()                       # syncs the collective
+        for i in range(SG):                                     # this rank's frames, split over the group's slots
+            rig.match_external_submit(all_desc[g].data_ptr(), counts, sets[i * fps:(i + 1) * fps], slot=g * SG + i)
+        for i in range(SG):
+            rig.match_wait(slot=g * SG + i)
 
     def barrier():
         if dist is not None:
@@ -191,14 +202,21 @@ def main():
         ksum["select_host"] += t["select_us"]
 
     def run_steps(nsteps, timed):
-        """nsteps steps = nsteps*S sub-batch jobs.  N == 1: rolling submission, S jobs always in flight (a slot is
-        resubmitted as soon as its previous job is collected), so step boundaries do not drain the pipeline."""
-        if N > 1:
-            for _ in range(nsteps):
-                step()
+        """nsteps steps = nsteps*F frames per rank.
+        N == 1: rolling submission, S jobs always in flight (a slot is resubmitted as soon as its previous job
+        is collected), so step boundaries do not drain the pipeline.
+        N > 1: three slot groups rotate; extraction of steps k+1 and k+2 is in flight while step k's descriptors
+        are all-gathered and matched."""
+        if DIST:
+            for k in range(min(G - 1, nsteps)):
+                extract_submit(k % G)
+            for k in range(nsteps):
+                if k + G - 1 < nsteps:
+                    extract_submit((k + G - 1) % G)     # the group step k-1 was matched on: free again
+                exchange_and_match(k % G)
                 if timed:
-                    for s in range(S):
-                        account(s)
+                    for i in range(SG):
+                        account((k % G) * SG + i)
             return
         jobs = nsteps * S
         for s in range(min(S, jobs)):
@@ -228,14 +246,14 @@ def main():
         return
 
     value = total_frames * args.steps / dt
-    launches = args.steps * S
+    launches = args.steps * SG
     # workload constants for the algorithmic-byte formulas
     lv = level_pixels(rig)
     Spx = sum(w * h for w, h in lv)
     S0, s_last = lv[0][0] * lv[0][1], lv[-1][0] * lv[-1][1]
     nimg_launch = per_slot
     Kc = np.mean([sum(len(rig.candidates(m, l, slot=0)[0]) for l in range(rig.nlevels)) for m in range(min(4, per_slot))])
-    K = np.mean([rig.features(m, slot=0)[1].shape[0] for m in range(min(4, per_slot))]) if N == 1 else NFEAT
+    K = np.mean([rig.features(m, slot=0)[1].shape[0] for m in range(min(4, per_slot))])
     gpu_kernels = {k: v for k, v in ksum.items() if k.startswith("k_")}
     dominant = max(gpu_kernels, key=gpu_kernels.get)
     avg_us = gpu_kernels[dominant] / launches
@@ -257,8 +275,8 @@ def main():
         "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_frame": round(dt / args.steps / total_frames * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "config": {"workload": "4-cam rig 1280x720, 2000 kpts/cam, extract + all-pairs intra-rig match (configs[1])",
-                   "frames_per_rank_per_step": F, "slots": S, "cameras": NCAMS, "nfeatures": NFEAT,
-                   "sharding": "single GPU" if N == 1 else "camera (c+f) mod N for extraction, RCCL all-gather of descriptors, frame f mod N for matching"},
+                   "frames_per_rank_per_step": F, "slots": S, "frames_per_launch": fps, "cameras": NCAMS, "nfeatures": NFEAT,
+                   "sharding": "single GPU" if not DIST else "camera (c+f) mod N for extraction, RCCL all-gather of descriptors, frame f mod N for matching"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(unit_bytes * units),
@@ -266,7 +284,7 @@ def main():
         "kernel_us_per_step": {k: round(v / args.steps, 2) for k, v in ksum.items()},
     }
 
-    if N == 1 and not args.no_cpu:
+    if N == 1 and not DIST and not args.no_cpu:
         ncpu = os.cpu_count()
         times, first = cpu_baseline(list(range(2 + args.cpu_frames)), NCAMS)
         times = np.array(times[2:])

@@ -199,6 +199,9 @@ int mcorb_get_pyramid_level(mcorb_t *e, int level, uint8_t *dst, int dst_stride,
 /* ------------------------------------------------------------------------- */
 /* ORBextractor::DescriptorDistance (ORBextractor.cpp:1202-1218); host, 0..256 */
 int mcorb_hamming256(const uint8_t a[32], const uint8_t b[32]);
+/* MultiCameraFrame::computeRepresentativeDesc (MultiCameraFrame.cpp:530-567): index of the descriptor
+ * (n x 32 bytes, n <= 64: one per camera of a track) with the least median distance to the rest. Host. */
+int mcorb_representative_desc(const uint8_t *descs, int n);
 /* DescriptorMatcher("BruteForce-Hamming")->knnMatch(q, t, out, 2)
  * (MultiCameraFrame.cpp:1053-1055; FrontEnd.cpp findInterMatches): host
  * descriptor arrays in, nq x 2 (trainIdx, distance) out, -1 = absent. */

@@ -49,6 +49,15 @@ def hamming256(a, b):
     return _lib.load().mcorb_hamming256(a.ctypes.data, b.ctypes.data)
 
 
+def representative_desc(descs):
+    """MultiCameraFrame::computeRepresentativeDesc (MultiCameraFrame.cpp:530-567): index of the chosen row."""
+    d = _u8(descs).reshape(-1, 32)
+    r = _lib.load().mcorb_representative_desc(d.ctypes.data, len(d))
+    if r < 0:
+        _lib.check(r)
+    return r
+
+
 class Rig:
     """One engine per GPU: `ncams` cameras of w x h, up to `max_frames` rig frames per batch."""
 

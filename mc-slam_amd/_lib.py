@@ -77,6 +77,7 @@ SIGNATURES = {
     "mcorb_get_tables": (_i, [C.POINTER(Params), _vp, _vp, _vp, _vp, _vp]),
     "mcorb_get_pyramid_level": (_i, [_vp, _i, _vp, _i, _ip, _ip]),
     "mcorb_hamming256": (_i, [_vp, _vp]),
+    "mcorb_representative_desc": (_i, [_vp, _i]),
     "mcorb_knn2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "mcorb_match_ratio": (_i, [_vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _i, _ip]),
     "mcorb_host_select": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i]),

@@ -500,6 +500,22 @@ int mcorb_hamming256(const uint8_t a[32], const uint8_t b[32])
            __builtin_popcountll(x[3] ^ y[3]);
 }
 
+// MultiCameraFrame::computeRepresentativeDesc (MultiCameraFrame.cpp:530-567): among n (<= 16) descriptors
+// of one track, the one with the least median Hamming distance to the others; first minimum wins.
+int mcorb_representative_desc(const uint8_t *descs, int n)
+{
+    if (!descs || n < 1 || n > 64) { set_error("representative_desc: bad argument"); return MCORB_E_ARG; }
+    int best_median = 0x7fffffff, best_idx = 0;
+    std::vector<int> row(n);
+    for (int i = 0; i < n; i++) {
+        for (int j = 0; j < n; j++) row[j] = i == j ? 0 : mcorb_hamming256(descs + (size_t)i * 32, descs + (size_t)j * 32);
+        std::sort(row.begin(), row.end());
+        const int median = row[(size_t)(0.5 * (n - 1))];
+        if (median < best_median) { best_median = median; best_idx = i; }
+    }
+    return best_idx;
+}
+
 static int knn2_host_arrays(mcorb_t *e, const uint8_t *q, int nq, const uint8_t *t, int nt, float thr, float ratio)
 {
     if (!e || nq < 0 || nt < 0 || (nq && !q) || (nt && !t)) { set_error("knn2: bad argument"); return MCORB_E_ARG; }
@@ -576,24 +592,6 @@ int mcorb_host_select(const uint32_t *packed, int n, int minX, int maxX, int min
     if (r > cap) { set_error("host_select: output too small"); return MCORB_E_CAP; }
     for (int i = 0; i < r; i++) out_idx[i] = perm[out[i]];
     return r;
-}
-
-// development aid (not part of the public header): time the two halves of mcorb_host_select
-int mcorb_dev_select_timing(const uint32_t *packed, int n, int minX, int maxX, int minY, int maxY, int N, int wCell,
-                            int hCell, int reps, double *us_sort, double *us_select)
-{
-    const SelectParams P = make_select_params(minX, maxX, minY, maxY, N, wCell, hCell);
-    static thread_local SelectScratch sc;
-    std::vector<uint32_t> sorted; std::vector<int> perm, bstart; std::vector<int> out((size_t)N + 80);
-    auto t0 = std::chrono::steady_clock::now();
-    for (int r = 0; r < reps; r++) host_bucket_sort(packed, n, P, sorted, perm, bstart);
-    auto t1 = std::chrono::steady_clock::now();
-    int m = 0;
-    for (int r = 0; r < reps; r++) m = select_octree(sorted.data(), bstart.data(), n, P, out.data(), sc);
-    auto t2 = std::chrono::steady_clock::now();
-    *us_sort = std::chrono::duration<double, std::micro>(t1 - t0).count() / reps;
-    *us_select = std::chrono::duration<double, std::micro>(t2 - t1).count() / reps;
-    return m;
 }
 
 int mcorb_host_resize_axis(int ssize, int dsize, int is_x, int32_t *quads)

@@ -127,7 +127,6 @@ struct Slot {
     bool busy = false, quit = false;
     int status = MCORB_OK;
     std::string err;
-    bool upload_pending = false;
 };
 
 class Rig {

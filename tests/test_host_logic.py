@@ -131,3 +131,13 @@ def test_synthetic_generator_c_equals_numpy(w, h, nc):
     a, b = pkg.synth_rig_frame(0, nc, 0, w, h), pkg.synth_rig_frame(0, max(nc, 2), 1, w, h)
     if nc >= 2:
         assert np.array_equal(a[:, 24:], b[:, :-24])
+
+
+def test_representative_descriptor_matches_oracle():
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 3, 4, 5, 8):
+        for _ in range(20):
+            base = rng.integers(0, 256, 32, dtype=np.uint8)
+            d = np.stack([base ^ (rng.integers(0, 256, 32, dtype=np.uint8) & rng.integers(0, 256, 32, dtype=np.uint8)
+                                  & rng.integers(0, 256, 32, dtype=np.uint8)) for _ in range(n)])
+            assert pkg.representative_desc(d) == O.representative_desc(d)
