@@ -553,8 +553,11 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
 {
     constexpr int TW = kBlurTW, TH = kBlurTH;
     constexpr int ID = TW / 4 + 2;          // input dwords per row: 4 bytes of apron on each side
+    constexpr int NP = (TH + 6) / 2;        // row pairs of the horizontal result
     __shared__ uint32_t in32[(TH + 6) * ID];
-    __shared__ __attribute__((aligned(16))) uint2 hb[(TH + 6) * (TW / 4)];   // 4 x u16 per entry
+    // horizontal result, two vertically adjacent rows per dword: hp[pair][x] = h[2*pair][x] | h[2*pair+1][x] << 16,
+    // so that the vertical pass is four v_dot2_u32_u16 per output pixel
+    __shared__ __attribute__((aligned(16))) uint32_t hp[NP * TW];
     const int tid = threadIdx.x;
     const int img = blockIdx.y;
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -568,51 +571,96 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const int x0 = tx * TW, y0 = ty * TH;
     const uint8_t *plane = pyr + (size_t)img * g.imgBytes + L.off;
 
-    for (int i = tid; i < (TH + 6) * ID; i += 256) {
-        const int r = i / ID, d = i - r * ID;
-        int sy = reflect101(y0 + r - 3, L.h);
-        sy = sy < 0 ? 0 : (sy >= L.h ? L.h - 1 : sy);
-        in32[i] = load4_reflect(plane, L.pitch, L.w, sy, x0 - 4 + 4 * d);
-    }
-    __syncthreads();
-    // horizontal: work item = (row, group of 4 output pixels); bytes b0..b11 = tile columns 4g .. 4g+11,
-    // output pixel j sits at tile column 4g+4+j and needs b[j+1 .. j+7]
-    for (int i = tid; i < (TH + 6) * (TW / 4); i += 256) {
-        const int r = i / (TW / 4), gx = i - r * (TW / 4);
-        const uint32_t d0 = in32[r * ID + gx], d1 = in32[r * ID + gx + 1], d2 = in32[r * ID + gx + 2];
-#define PK(hi, lo, sel) __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, sel))
-        const u16x2 P1 = PK(d1, d0, 0x0c020c01u), P2 = PK(d1, d0, 0x0c030c02u), P3 = PK(d1, d0, 0x0c040c03u);
-        const u16x2 P4 = PK(d1, d0, 0x0c050c04u), P5 = PK(d1, d0, 0x0c060c05u), P6 = PK(d1, d0, 0x0c070c06u);
-        const u16x2 P7 = PK(d2, d1, 0x0c040c03u), P8 = PK(d2, d1, 0x0c050c04u), P9 = PK(d2, d1, 0x0c060c05u);
-#undef PK
-        const u16x2 k18 = {18, 18}, k34 = {34, 34}, k48 = {48, 48}, k56 = {56, 56};
-        const u16x2 o01 = k18 * (P1 + P7) + k34 * (P2 + P6) + k48 * (P3 + P5) + k56 * P4;
-        const u16x2 o23 = k18 * (P3 + P9) + k34 * (P4 + P8) + k48 * (P5 + P7) + k56 * P6;
-        hb[i] = uint2{__builtin_bit_cast(uint32_t, o01), __builtin_bit_cast(uint32_t, o23)};
-    }
-    __syncthreads();
-    // vertical: thread = 4 columns x 4 rows, sliding over 10 rows of the horizontal result
-    const int gx = tid & (TW / 4 - 1), rg = tid / (TW / 4);
-    uint32_t h[10][4];
+    constexpr int NLD = ((TH + 6) * ID + 255) / 256;
+    if (x0 >= 4 && x0 + TW + 4 <= L.w && y0 >= 3 && y0 + TH + 3 <= L.h) {
+        // interior tile (the common case): no border handling, all loads issued before the first LDS store
+        const uint8_t *src = plane + (size_t)(y0 - 3) * L.pitch + (x0 - 4);
+        uint32_t v[NLD];
 #pragma unroll
-    for (int r = 0; r < 10; r++) {
-        const uint2 v = hb[(rg * 4 + r) * (TW / 4) + gx];
-        h[r][0] = v.x & 0xffffu; h[r][1] = v.x >> 16; h[r][2] = v.y & 0xffffu; h[r][3] = v.y >> 16;
+        for (int k = 0; k < NLD; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / ID, d = i - r * ID;
+            v[k] = i < (TH + 6) * ID ? *reinterpret_cast<const uint32_t *>(src + (size_t)r * L.pitch + 4 * d) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int i = tid + 256 * k;
+            if (i < (TH + 6) * ID) in32[i] = v[k];
+        }
+    } else {
+        for (int i = tid; i < (TH + 6) * ID; i += 256) {
+            const int r = i / ID, d = i - r * ID;
+            int sy = reflect101(y0 + r - 3, L.h);
+            sy = sy < 0 ? 0 : (sy >= L.h ? L.h - 1 : sy);
+            in32[i] = load4_reflect(plane, L.pitch, L.w, sy, x0 - 4 + 4 * d);
+        }
     }
+    __syncthreads();
+    // horizontal: work item = (row pair, group of 4 output pixels); bytes b0..b11 = tile columns 4g .. 4g+11,
+    // output pixel j sits at tile column 4g+4+j and needs b[j+1 .. j+7]; packed u16 arithmetic is exact (<= 65280)
+    for (int i = tid; i < NP * (TW / 4); i += 256) {
+        const int p = i / (TW / 4), gx = i - p * (TW / 4);
+        uint32_t o01[2], o23[2];
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const uint32_t *row = in32 + (2 * p + rr) * ID + gx;
+            const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];
+#define PK(hi, lo, sel) __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, sel))
+            const u16x2 P1 = PK(d1, d0, 0x0c020c01u), P2 = PK(d1, d0, 0x0c030c02u), P3 = PK(d1, d0, 0x0c040c03u);
+            const u16x2 P4 = PK(d1, d0, 0x0c050c04u), P5 = PK(d1, d0, 0x0c060c05u), P6 = PK(d1, d0, 0x0c070c06u);
+            const u16x2 P7 = PK(d2, d1, 0x0c040c03u), P8 = PK(d2, d1, 0x0c050c04u), P9 = PK(d2, d1, 0x0c060c05u);
+#undef PK
+            const u16x2 k18 = {18, 18}, k34 = {34, 34}, k48 = {48, 48}, k56 = {56, 56};
+            o01[rr] = __builtin_bit_cast(uint32_t, (u16x2)(k18 * (P1 + P7) + k34 * (P2 + P6) + k48 * (P3 + P5) + k56 * P4));
+            o23[rr] = __builtin_bit_cast(uint32_t, (u16x2)(k18 * (P3 + P9) + k34 * (P4 + P8) + k48 * (P5 + P7) + k56 * P6));
+        }
+        uint4 v;
+        v.x = __builtin_amdgcn_perm(o01[1], o01[0], 0x05040100u);   // (h[r][x0],   h[r+1][x0])
+        v.y = __builtin_amdgcn_perm(o01[1], o01[0], 0x07060302u);   // x0 + 1
+        v.z = __builtin_amdgcn_perm(o23[1], o23[0], 0x05040100u);   // x0 + 2
+        v.w = __builtin_amdgcn_perm(o23[1], o23[0], 0x07060302u);   // x0 + 3
+        *reinterpret_cast<uint4 *>(hp + p * TW + 4 * gx) = v;
+    }
+    __syncthreads();
+    // vertical: thread = 4 columns x 4 rows from five row pairs; taps {18,34,48,56,48,34,18} paired with the rows
+    const int gx = tid & (TW / 4 - 1), rg = tid / (TW / 4);
+    uint32_t P[5][4];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(hp + (2 * rg + q) * TW + 4 * gx);
+        P[q][0] = v.x; P[q][1] = v.y; P[q][2] = v.z; P[q][3] = v.w;
+    }
+#define KK(lo, hi) (u16x2{(unsigned short)(lo), (unsigned short)(hi)})
+#define DOT(a, k, c) __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), k, c, false)
     uint8_t *oplane = blur + (size_t)img * g.imgBytes + L.off;
     const int x = x0 + 4 * gx;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        uint32_t out = 0;
+        uint32_t acc[4];
+        const int q = k >> 1;   // first row pair of this output row
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            const uint32_t acc = 18u * (h[k][j] + h[k + 6][j]) + 34u * (h[k + 1][j] + h[k + 5][j]) +
-                                 48u * (h[k + 2][j] + h[k + 4][j]) + 56u * h[k + 3][j];
-            out |= ((acc + 32768u) >> 16) << (8 * j);
+            uint32_t a = 32768u;
+            if ((k & 1) == 0) {   // rows 2q .. 2q+6
+                a = DOT(P[q][j], KK(18, 34), a);
+                a = DOT(P[q + 1][j], KK(48, 56), a);
+                a = DOT(P[q + 2][j], KK(48, 34), a);
+                a = DOT(P[q + 3][j], KK(18, 0), a);
+            } else {              // rows 2q+1 .. 2q+7
+                a = DOT(P[q][j], KK(0, 18), a);
+                a = DOT(P[q + 1][j], KK(34, 48), a);
+                a = DOT(P[q + 2][j], KK(56, 48), a);
+                a = DOT(P[q + 3][j], KK(34, 18), a);
+            }
+            acc[j] = a;
         }
+        // (acc + 32768) >> 16 fits a byte: pick byte 2 of each accumulator
+        const uint32_t out = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
         const int y = y0 + rg * 4 + k;
         if (x < L.w && y < L.h) *reinterpret_cast<uint32_t *>(oplane + (size_t)y * L.pitch + x) = out;
     }
+#undef KK
+#undef DOT
 }
 
 // ---------------------------------------------------------------------------
@@ -781,6 +829,28 @@ __global__ __launch_bounds__(256) void k_describe_oriented(const uint8_t *__rest
 // "two smallest keys" exactly knnMatch's order, including its lowest-index
 // tie-break, so chunks can be reduced in any order.
 // ---------------------------------------------------------------------------
+// popcount(x) + acc in one instruction; chaining the eight words of a 256-bit XOR through the
+// accumulator operand saves the separate adds the compiler otherwise emits
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t hamming256(const ulonglong4 &a, const ulonglong4 &b)
+{
+    const unsigned long long x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
+    uint32_t d = __builtin_popcount((uint32_t)x0);
+    d = bcnt_acc((uint32_t)(x0 >> 32), d);
+    d = bcnt_acc((uint32_t)x1, d);
+    d = bcnt_acc((uint32_t)(x1 >> 32), d);
+    d = bcnt_acc((uint32_t)x2, d);
+    d = bcnt_acc((uint32_t)(x2 >> 32), d);
+    d = bcnt_acc((uint32_t)x3, d);
+    d = bcnt_acc((uint32_t)(x3 >> 32), d);
+    return d;
+}
+
 __device__ __forceinline__ void knn_insert(uint32_t key, uint32_t &k0, uint32_t &k1)
 {
     const uint32_t lo = key < k0 ? key : k0;
@@ -820,16 +890,17 @@ __global__ __launch_bounds__(64) void k_knn2(const uint8_t *__restrict__ desc, c
             v[u] = ulonglong4{0, 0, 0, 0};
             if (q0 + 64 * u < nq) v[u] = *reinterpret_cast<const ulonglong4 *>(desc + ((size_t)qt.x * kcap + q0 + 64 * u) * 32);
         }
-#pragma unroll 2
-        for (int j = 0; j < tn; j++) {
+        auto step = [&](int j) {
             const ulonglong4 t = tr[j];
             const uint32_t tj = (uint32_t)(t0 + j);
 #pragma unroll
-            for (int u = 0; u < kKnnQpl; u++) {
-                const uint32_t d = __popcll(v[u].x ^ t.x) + __popcll(v[u].y ^ t.y) + __popcll(v[u].z ^ t.z) + __popcll(v[u].w ^ t.w);
-                knn_insert((d << 16) | tj, k0[u], k1[u]);
-            }
+            for (int u = 0; u < kKnnQpl; u++) knn_insert((hamming256(v[u], t) << 16) | tj, k0[u], k1[u]);
+        };
+        int j = 0;
+        for (; j + 4 <= tn; j += 4) {   // manual unroll: four broadcast LDS reads in flight per iteration
+            step(j); step(j + 1); step(j + 2); step(j + 3);
         }
+        for (; j < tn; j++) step(j);
     }
     uint2 *out = part + ((size_t)pair * nchunks + chunk) * kcap;
 #pragma unroll
