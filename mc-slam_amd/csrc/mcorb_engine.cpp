@@ -318,11 +318,11 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     // LDS source window of one resize workgroup (256 x kResizeTileH outputs): widest column span / tallest row span per level
     for (int l = 1; l < geom.nlevels; l++) {
         const LevelGeom &D = geom.lv[l];
-        int maxc = 4, maxr = 2;
+        int maxc = 16, maxr = 2;
         for (int bx0 = 0; bx0 < D.w; bx0 += 256) {
             const int bx1 = std::min(bx0 + 255, D.w - 1);
-            const int a = taps[D.xtab + bx0].s0 & ~3, b = taps[D.xtab + bx1].s1;
-            maxc = std::max(maxc, ((b - a) / 4 + 1) * 4);
+            const int a = taps[D.xtab + bx0].s0 & ~15, b = taps[D.xtab + bx1].s1;
+            maxc = std::max(maxc, ((b - a) / 16 + 1) * 16);
         }
         for (int by0 = 0; by0 < D.h; by0 += kResizeTileH) {
             const int by1 = std::min(by0 + kResizeTileH - 1, D.h - 1);

@@ -17,6 +17,11 @@ namespace mcorb {
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// number of set bits of a wave mask below this lane, plus acc (v_mbcnt_lo/hi: two instructions)
+__device__ __forceinline__ int lane_rank(unsigned long long mask, int acc = 0)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, (uint32_t)acc));
+}
 // XCD-aware work index: workgroups b and b+8 share an XCD (and its L2) under the observed round-robin
 // placement, so give each XCD one contiguous eighth of the work items -- spatial neighbours (cells or
 // tiles that re-read the same 64-B lines for their halos) then hit in the same L2.  Bijective for any n;
@@ -86,18 +91,19 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
     const int tid = threadIdx.x;
     const int bx0 = blockIdx.x * 256, by0 = blockIdx.y * kResizeRows;
     const int bx1 = min(bx0 + 255, D.w - 1), by1 = min(by0 + kResizeRows - 1, D.h - 1);
-    // source window of this workgroup (tables are monotone)
-    const int sx0 = tabs[D.xtab + bx0].s0 & ~3, sx1 = tabs[D.xtab + bx1].s1;
+    // source window of this workgroup (tables are monotone); 16-byte aligned so it is filled with dwordx4 loads
+    const int sx0 = tabs[D.xtab + bx0].s0 & ~15, sx1 = tabs[D.xtab + bx1].s1;
     const int sy0 = tabs[D.ytab + by0].s0, sy1 = tabs[D.ytab + by1].s1;
-    const int nd = ((sx1 - sx0) >> 2) + 1, nr = sy1 - sy0 + 1;   // nd*4 <= srcPitch, nr <= srcRows by construction
+    const int nq = ((sx1 - sx0) >> 4) + 1, nr = sy1 - sy0 + 1;   // nq*16 <= srcPitch, nr <= srcRows by construction
     {
         const uint8_t *sp = base + S.off + (size_t)sy0 * S.pitch + sx0;
-        uint32_t *w32 = reinterpret_cast<uint32_t *>(win);
-        const int pd = srcPitch >> 2;
-        const float rcp_pd = 1.0f / (float)pd;
-        for (int i = tid; i < nr * pd; i += 256) {
-            const int r = (int)(((float)i + 0.5f) * rcp_pd), d = i - r * pd;
-            if (d < nd) w32[i] = *reinterpret_cast<const uint32_t *>(sp + (size_t)r * S.pitch + 4 * d);
+        uint4 *w128 = reinterpret_cast<uint4 *>(win);
+        const int pq = srcPitch >> 4;
+        const float rcp_pq = 1.0f / (float)pq;
+        for (int i = tid; i < nr * pq; i += 256) {
+            const int r = (int)(((float)i + 0.5f) * rcp_pq), q = i - r * pq;
+            // rows are 64-byte aligned and padded to a multiple of 64 bytes, so a 16-byte load never leaves the row
+            if (q < nq) w128[i] = *reinterpret_cast<const uint4 *>(sp + (size_t)r * S.pitch + 16 * q);
         }
     }
     __syncthreads();
@@ -116,9 +122,10 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
         a1[k] = ok ? (int)(short)(tw[2 * k + 1] >> 16) : 0;
     }
     const uint32_t mask = dx4 + 4 > D.w ? 0xffffffffu >> (8 * (dx4 + 4 - D.w)) : 0xffffffffu;   // keep the row padding zero
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the row taps become scalar loads
 #pragma unroll
     for (int rr = 0; rr < kResizeRows / 4; rr++) {
-        const int dy = by0 + (tid >> 6) + 4 * rr;
+        const int dy = by0 + wave + 4 * rr;
         if (dy >= D.h) break;
         const ResizeTap ty = tabs[D.ytab + dy];
         const uint8_t *S0 = win + (ty.s0 - sy0) * srcPitch;
@@ -267,7 +274,6 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 
     const float rcp_tp = 1.0f / (float)TP;
     const int tlo = iniTh < minTh ? iniTh : minTh;
-    const unsigned long long lt = (1ull << lane) - 1ull;
 
     // ---- pass 1: 4-point test, 4 horizontally adjacent pixels per lane: five aligned LDS dwords
     //      (centre, left, right, 3 rows up, 3 rows down) feed packed 16-bit min/max; survivors are
@@ -281,42 +287,39 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         const int cmin = ph + 3, cmax = ph + 3 + wi;   // valid tile columns [cmin, cmax)
         const s16x2 zero = {0, 0};
         for (int w0 = 0; w0 < nw; w0 += 64) {
-            const int w = w0 + lane;
-            bool c0 = false, c1 = false, c2 = false, c3 = false;
-            int pos = 0;
-            if (w < nw) {
-                const int r = (int)(((float)w + 0.5f) * rcp_ng), gq = g0 + (w - r * ng);
-                const int di = (r + 3) * nd + gq;
-                const uint32_t C = t32[di], Cl = t32[di - 1], Cr = t32[di + 1], U = t32[di - 3 * nd], Dn = t32[di + 3 * nd];
-                const uint32_t Lf = __builtin_amdgcn_alignbyte(C, Cl, 1);   // columns 4g-3 .. 4g
-                const uint32_t Rt = __builtin_amdgcn_alignbyte(Cr, C, 3);   // columns 4g+3 .. 4g+6
-                pos = (r + 3) * TP + 4 * gq;
-                int m[4];
+            const int wr = w0 + lane;
+            const int w = wr < nw ? wr : nw - 1;   // tail lanes redo the last item; their results are masked out
+            const int r = (int)(((float)w + 0.5f) * rcp_ng), gq = g0 + (w - r * ng);
+            const int di = (r + 3) * nd + gq;
+            const uint32_t C = t32[di], Cl = t32[di - 1], Cr = t32[di + 1], U = t32[di - 3 * nd], Dn = t32[di + 3 * nd];
+            const uint32_t Lf = __builtin_amdgcn_alignbyte(C, Cl, 1);   // columns 4g-3 .. 4g
+            const uint32_t Rt = __builtin_amdgcn_alignbyte(Cr, C, 3);   // columns 4g+3 .. 4g+6
+            const int pos = (r + 3) * TP + 4 * gq;
+            s16x2 mm[2];
 #pragma unroll
-                for (int hgh = 0; hgh < 2; hgh++) {
-                    const uint32_t sel = hgh ? 0x0c030c02u : 0x0c010c00u;
+            for (int hgh = 0; hgh < 2; hgh++) {
+                const uint32_t sel = hgh ? 0x0c030c02u : 0x0c010c00u;
 #define UNP(X) __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, X, sel))
-                    const s16x2 V = UNP(C);
-                    const s16x2 d0 = V - UNP(Dn), d4 = V - UNP(Rt), d8 = V - UNP(U), d12 = V - UNP(Lf);
+                const s16x2 V = UNP(C);
+                const s16x2 d0 = V - UNP(Dn), d4 = V - UNP(Rt), d8 = V - UNP(U), d12 = V - UNP(Lf);
 #undef UNP
-                    const s16x2 lo = __builtin_elementwise_max(
-                        __builtin_elementwise_max(__builtin_elementwise_min(d0, d4), __builtin_elementwise_min(d4, d8)),
-                        __builtin_elementwise_max(__builtin_elementwise_min(d8, d12), __builtin_elementwise_min(d12, d0)));
-                    const s16x2 hi2 = __builtin_elementwise_min(
-                        __builtin_elementwise_min(__builtin_elementwise_max(d0, d4), __builtin_elementwise_max(d4, d8)),
-                        __builtin_elementwise_min(__builtin_elementwise_max(d8, d12), __builtin_elementwise_max(d12, d0)));
-                    const s16x2 mm = __builtin_elementwise_max(lo, zero - hi2);
-                    m[2 * hgh] = mm.x;
-                    m[2 * hgh + 1] = mm.y;
-                }
-                const int col = 4 * gq;
-                c0 = m[0] > tlo && col >= cmin && col < cmax;
-                c1 = m[1] > tlo && col + 1 >= cmin && col + 1 < cmax;
-                c2 = m[2] > tlo && col + 2 >= cmin && col + 2 < cmax;
-                c3 = m[3] > tlo && col + 3 >= cmin && col + 3 < cmax;
+                const s16x2 lo = __builtin_elementwise_max(
+                    __builtin_elementwise_max(__builtin_elementwise_min(d0, d4), __builtin_elementwise_min(d4, d8)),
+                    __builtin_elementwise_max(__builtin_elementwise_min(d8, d12), __builtin_elementwise_min(d12, d0)));
+                const s16x2 hi2 = __builtin_elementwise_min(
+                    __builtin_elementwise_min(__builtin_elementwise_max(d0, d4), __builtin_elementwise_max(d4, d8)),
+                    __builtin_elementwise_min(__builtin_elementwise_max(d8, d12), __builtin_elementwise_max(d12, d0)));
+                mm[hgh] = __builtin_elementwise_max(lo, zero - hi2);
             }
+            // only the first / last group of a row can hold columns outside [cmin, cmax)
+            const int col = 4 * gq;
+            const bool in = wr < nw;
+            const bool c0 = in && mm[0].x > tlo && col >= cmin && col < cmax;
+            const bool c1 = in && mm[0].y > tlo && col + 1 >= cmin && col + 1 < cmax;
+            const bool c2 = in && mm[1].x > tlo && col + 2 >= cmin && col + 2 < cmax;
+            const bool c3 = in && mm[1].y > tlo && col + 3 >= cmin && col + 3 < cmax;
             const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1), b2 = __ballot(c2), b3 = __ballot(c3);
-            int o = nA + __popcll(b0 & lt) + __popcll(b1 & lt) + __popcll(b2 & lt) + __popcll(b3 & lt);
+            int o = lane_rank(b3, lane_rank(b2, lane_rank(b1, lane_rank(b0, nA))));
             if (c0) work[o++] = (uint16_t)pos;
             if (c1) work[o++] = (uint16_t)(pos + 1);
             if (c2) work[o++] = (uint16_t)(pos + 2);
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         }
         const unsigned long long b = __ballot(cand);
         __syncthreads();
-        if (cand) work[nB + __popcll(b & lt)] = (uint16_t)pos;
+        if (cand) work[lane_rank(b, nB)] = (uint16_t)pos;
         nB += __popcll(b);
     }
     __syncthreads();
@@ -375,7 +378,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             }
             const unsigned long long b = __ballot(keep);
             if (keep) {
-                const int o = total + __popcll(b & lt);
+                const int o = lane_rank(b, total);
                 const int yy = (int)(((float)pos + 0.5f) * rcp_tp), xx = pos - yy * TP - ph;   // ROI coordinates
                 // keypoint coordinates relative to minBorder: FAST's ROI coordinate + cell origin (:864-865)
                 if (o < g.cellCap) dst[o] = pack_cand(xx + cj * L.wCell, yy + ci * L.hCell, a - 1);
@@ -977,7 +980,9 @@ void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, i
         tileBytes = tileBytes > tb ? tileBytes : tb;
     }
     tileBytes = (tileBytes + 15) & ~15;
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(64), 4 * tileBytes, st, pyr, g, iniTh, minTh, tileBytes, cell_kp,
+    int maxNi = 0;   // interior pixels of a cell = worst-case length of the survivor list (u16 entries)
+    for (int l = 0; l < g.nlevels; l++) maxNi = maxNi > g.lv[l].wCell * g.lv[l].hCell ? maxNi : g.lv[l].wCell * g.lv[l].hCell;
+    hipLaunchKernelGGL(k_fast_cells, grid, dim3(64), 2 * tileBytes + ((2 * maxNi + 15) & ~15), st, pyr, g, iniTh, minTh, tileBytes, cell_kp,
                        cell_cnt);
 }
 
