@@ -122,7 +122,7 @@ def main():
     F = args.frames if args.frames else (72 if DIST else 48)
     S = args.slots if args.slots else (9 if DIST else 6)
     S = max(1, min(S, F))
-    G = 3 if DIST else 1               # slot groups: with N > 1 two groups extract steps k+1, k+2 while the third matches step k
+    G = int(os.environ.get("MCORB_BENCH_GROUPS", "3")) if DIST else 1   # slot groups: with N > 1 G-1 groups extract steps k+1.. while one matches step k
     if DIST and S % G:
         S += G - S % G
     SG = S // G                        # slots per group
