@@ -211,6 +211,32 @@ int mcorb_match_ratio(mcorb_t *e, const uint8_t *q, int nq, const uint8_t *t, in
                       float dist_thresh, float ratio, uint32_t *idx1, uint32_t *idx2, int cap, int *n_out);
 
 /* ------------------------------------------------------------------------- */
+/* DBoW2 vocabulary: transform(features, BowVector, FeatureVector, levelsup)  */
+/* (MultiCameraFrame.cpp:257, FrontEnd.cpp:525,929).  The    */
+/* tree descent runs on the GPU; the std::map-ordered weight accumulation and */
+/* normalisation on the host, in feature order.                               */
+/* ------------------------------------------------------------------------- */
+typedef struct mcorb_vocab mcorb_vocab;
+/* nodes 1..nnodes in file order (node 0 is the root): parent id, leaf flag, 32-byte descriptor, weight.
+ * scoring: 0 L1_NORM, 1 L2_NORM, 2 CHI_SQUARE, 3 KL, 4 BHATTACHARYYA, 5 DOT_PRODUCT;
+ * weighting: 0 TF_IDF, 1 TF, 2 IDF, 3 BINARY (DBoW2's enums; ORBvoc.txt is "10 6 0 0"). */
+int mcorb_vocab_create(int k, int L, int scoring, int weighting, const int32_t *parent, const uint8_t *is_leaf,
+                       const uint8_t *desc, const double *weight, int nnodes, int device, mcorb_vocab **out);
+/* TemplatedVocabulary::loadFromTextFile (FrontEnd.h:137-138) */
+int mcorb_vocab_load_text(const char *path, int device, mcorb_vocab **out);
+void mcorb_vocab_destroy(mcorb_vocab *v);
+int mcorb_vocab_info(const mcorb_vocab *v, int *k, int *L, int *nnodes, int *nwords);
+/* transform n descriptors (host, n x 32).  BowVector: (word id, value) ascending by id;
+ * FeatureVector: node ids ascending, fv_offsets[i]..fv_offsets[i+1] index fv_feats (feature indices). */
+int mcorb_vocab_transform(mcorb_vocab *v, const uint8_t *desc, int n, int levelsup, uint32_t *bow_ids, double *bow_vals,
+                          int bow_cap, int *nbow, uint32_t *fv_nodes, int32_t *fv_offsets, int fv_cap, int *nfv,
+                          int32_t *fv_feats, int feat_cap);
+/* same for image m of a rig slot, reading the descriptors where extraction left them in HBM */
+int mcorb_rig_transform_image(mcorb_rig *r, int slot, int m, mcorb_vocab *v, int levelsup, uint32_t *bow_ids,
+                              double *bow_vals, int bow_cap, int *nbow, uint32_t *fv_nodes, int32_t *fv_offsets,
+                              int fv_cap, int *nfv, int32_t *fv_feats, int feat_cap);
+
+/* ------------------------------------------------------------------------- */
 /* Host stages exposed for the CPU test-suite (no device needed)              */
 /* ------------------------------------------------------------------------- */
 /* The engine's quad-tree selection, DistributeOctTree's equivalent (ORBextractor.cpp:554-778), run

@@ -331,6 +331,74 @@ class ORBextractor:
         return np.array(mA, np.uint32), np.array(mB, np.uint32), book
 
 
+class ORBVocabulary:
+    """DBoW2::ORBVocabulary (MCSlam/include/MCSlam/ORBVocabulary.h:21-30) as far as this path uses it:
+    loadFromTextFile + transform(features, BowVector, FeatureVector, levelsup)."""
+
+    def __init__(self, device=0):
+        self.L_ = _lib.load()
+        self.device = device
+        self.h = None
+
+    def loadFromTextFile(self, filename):
+        h = C.c_void_p()
+        st = self.L_.mcorb_vocab_load_text(filename.encode(), self.device, C.byref(h))
+        if st != OK:
+            return False          # the reference returns false and the caller exits (FrontEnd.h:139-143)
+        self.close()
+        self.h = h
+        return True
+
+    def create(self, k, L, scoring, weighting, parent, is_leaf, desc, weight):
+        parent = np.ascontiguousarray(parent, np.int32)
+        is_leaf = np.ascontiguousarray(is_leaf, np.uint8)
+        desc = _u8(desc).reshape(-1, 32)
+        weight = np.ascontiguousarray(weight, np.float64)
+        h = C.c_void_p()
+        _lib.check(self.L_.mcorb_vocab_create(k, L, scoring, weighting, parent.ctypes.data, is_leaf.ctypes.data,
+                                              desc.ctypes.data, weight.ctypes.data, len(parent), self.device, C.byref(h)))
+        self.close()
+        self.h = h
+        return self
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L_.mcorb_vocab_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self):
+        k, L, nn, nw = (C.c_int() for _ in range(4))
+        _lib.check(self.L_.mcorb_vocab_info(self.h, C.byref(k), C.byref(L), C.byref(nn), C.byref(nw)))
+        return dict(k=k.value, L=L.value, nodes=nn.value, words=nw.value)
+
+    def _call(self, fn, head, n, levelsup):
+        cap = max(n, 1)
+        ids, vals = np.zeros(cap, np.uint32), np.zeros(cap, np.float64)
+        nodes, offs, feats = np.zeros(cap, np.uint32), np.zeros(cap + 1, np.int32), np.zeros(cap, np.int32)
+        nb, nf = C.c_int(), C.c_int()
+        _lib.check(fn(*head, levelsup, ids.ctypes.data, vals.ctypes.data, cap, C.byref(nb), nodes.ctypes.data,
+                      offs.ctypes.data, cap, C.byref(nf), feats.ctypes.data, cap))
+        bow = (ids[:nb.value].copy(), vals[:nb.value].copy())
+        fv = {int(nodes[i]): feats[offs[i]:offs[i + 1]].copy() for i in range(nf.value)}
+        return bow, fv
+
+    def transform(self, features, levelsup=4):
+        """-> BowVector as (word ids ascending, values), FeatureVector as {node id: feature indices}."""
+        d = _u8(features).reshape(-1, 32)
+        return self._call(self.L_.mcorb_vocab_transform, (self.h, d.ctypes.data, len(d)), len(d), levelsup)
+
+    def transform_rig_image(self, rig, m, slot=0, levelsup=4):
+        """transform() of image m's descriptors straight from the rig's HBM buffers (MultiCameraFrame.cpp:257)."""
+        n = rig.L.mcorb_rig_num_keypoints(rig.h_rig, slot, m)
+        return self._call(self.L_.mcorb_rig_transform_image, (rig.h_rig, slot, m, self.h), max(n, 0), levelsup)
+
+
 class IntraMatch:
     """MultiCameraFrame.h:42-57 (matchIndex widened from 5 to ncams entries)."""
 

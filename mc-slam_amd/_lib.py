@@ -80,6 +80,12 @@ SIGNATURES = {
     "mcorb_representative_desc": (_i, [_vp, _i]),
     "mcorb_knn2": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp]),
     "mcorb_match_ratio": (_i, [_vp, _vp, _i, _vp, _i, _f, _f, _vp, _vp, _i, _ip]),
+    "mcorb_vocab_create": (_i, [_i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "mcorb_vocab_load_text": (_i, [C.c_char_p, _i, C.POINTER(_vp)]),
+    "mcorb_vocab_destroy": (None, [_vp]),
+    "mcorb_vocab_info": (_i, [_vp, _ip, _ip, _ip, _ip]),
+    "mcorb_vocab_transform": (_i, [_vp, _vp, _i, _i, _vp, _vp, _i, _ip, _vp, _vp, _i, _ip, _vp, _i]),
+    "mcorb_rig_transform_image": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _ip, _vp, _vp, _i, _ip, _vp, _i]),
     "mcorb_host_select": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i]),
     "mcorb_host_resize_axis": (_i, [_i, _i, _i, _vp]),
     "mcorb_host_geometry": (_i, [C.POINTER(Params), _i, _i, _vp]),

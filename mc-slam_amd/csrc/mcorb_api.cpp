@@ -9,10 +9,6 @@
 
 using namespace mcorb;
 
-struct mcorb_rig {
-    Rig rig;
-};
-
 struct mcorb_extractor {
     mcorb_params params;
     Rig *rig = nullptr;   // rebuilt when the image size changes

@@ -162,3 +162,8 @@ private:
 };
 
 }  // namespace mcorb
+
+// the C handle of include/mcorb.h
+struct mcorb_rig {
+    mcorb::Rig rig;
+};

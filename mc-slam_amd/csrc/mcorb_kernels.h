@@ -32,4 +32,7 @@ void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, co
 void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const int2 *pairs, int npairs, int kcap,
                  uint2 *part, float dist_thresh, float ratio, KnnRow *out, hipEvent_t ev_mid);
 
+void launch_bow_descend(hipStream_t st, const uint8_t *desc, int n, const int *child_start, const int *child_count,
+                        const void *child_desc, const int *child_id, int nid_level, int2 *out);
+
 }  // namespace mcorb

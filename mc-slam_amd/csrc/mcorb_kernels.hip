@@ -949,6 +949,38 @@ __global__ __launch_bounds__(256) void k_knn2_finalize(const uint2 *__restrict__
 }
 
 // ---------------------------------------------------------------------------
+// DBoW2 vocabulary-tree descent (TemplatedVocabulary::transform's per-feature part, used by
+// MultiCameraFrame::extractFeatureSingle, MultiCameraFrame.cpp:257): from the root, move to the child
+// with the smallest Hamming distance (strict '<': the first child wins ties) until a leaf; remember the
+// node reached at depth `nid_level`.  One descriptor per lane; the children of a node are stored
+// contiguously (descriptor + node id), k*32 bytes per step.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bow_descend(const uint8_t *__restrict__ desc, int n, const int *__restrict__ child_start,
+                                                     const int *__restrict__ child_count, const ulonglong4 *__restrict__ child_desc,
+                                                     const int *__restrict__ child_id, int nid_level, int2 *__restrict__ out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const ulonglong4 q = *reinterpret_cast<const ulonglong4 *>(desc + (size_t)i * 32);
+    int node = 0, nid = 0, level = 0;
+    int cc = child_count[0];
+    while (cc > 0) {
+        ++level;
+        const int cs = child_start[node];
+        uint32_t best = 0xffffffffu;
+        int bj = 0;
+        for (int j = 0; j < cc; j++) {
+            const uint32_t d = hamming256(q, child_desc[cs + j]);
+            if (d < best) { best = d; bj = j; }
+        }
+        node = child_id[cs + bj];
+        if (level == nid_level) nid = node;
+        cc = child_count[node];
+    }
+    out[i] = int2{node, nid};
+}
+
+// ---------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------
 hipError_t upload_umax(const int umax[16]) { return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax, 16 * sizeof(int)); }
@@ -1026,6 +1058,14 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
     if (ev_mid) (void)hipEventRecord(ev_mid, st);
     dim3 g2((kcap + 255) / 256, npairs);
     hipLaunchKernelGGL(k_knn2_finalize, g2, dim3(256), 0, st, part, counts, pairs, kcap, nchunks, dist_thresh, ratio, out);
+}
+
+void launch_bow_descend(hipStream_t st, const uint8_t *desc, int n, const int *child_start, const int *child_count,
+                        const void *child_desc, const int *child_id, int nid_level, int2 *out)
+{
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_bow_descend, dim3((n + 255) / 256), dim3(256), 0, st, desc, n, child_start, child_count,
+                       reinterpret_cast<const ulonglong4 *>(child_desc), child_id, nid_level, out);
 }
 
 }  // namespace mcorb

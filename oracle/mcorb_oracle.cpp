@@ -1097,3 +1097,103 @@ extern "C" int orc_representative_desc(const uint8_t *descs, int n)
     }
     return BestIdx;
 }
+
+/* ------------------------------------------------------------------------- */
+/* DBoW2 TemplatedVocabulary<FORB>::transform (un-vendored dependency of the        */
+/* reference, restated from the published algorithm -- call sites MultiCameraFrame.cpp:257,      */
+/* FrontEnd.cpp:525,929; vocabulary layout as loadFromTextFile builds it, FrontEnd.h:137-138)    */
+/* ------------------------------------------------------------------------- */
+#include <map>
+namespace {
+struct VNode {
+    int id = 0, parent = 0, word_id = 0;
+    double weight = 0;
+    std::vector<int> children;
+    uint8_t descriptor[32];
+    bool isLeaf() const { return children.empty(); }
+};
+}   // namespace
+
+extern "C" int orc_bow_transform(int k, int L, int scoring, int weighting, const int32_t *parent, const uint8_t *is_leaf,
+                                 const uint8_t *ndesc, const double *nweight, int nnodes, const uint8_t *feats, int nf,
+                                 int levelsup, uint32_t *bow_ids, double *bow_vals, int *nbow, uint32_t *fv_nodes,
+                                 int32_t *fv_offsets, int *nfv, int32_t *fv_feats)
+{
+    (void)k;
+    /* loadFromTextFile: node ids in file order, children in file order, words numbered in file order */
+    std::vector<VNode> m_nodes(1);
+    m_nodes[0].id = 0;
+    int nwords = 0;
+    for (int i = 0; i < nnodes; i++) {
+        int nid = (int)m_nodes.size();
+        m_nodes.resize(m_nodes.size() + 1);
+        m_nodes[nid].id = nid;
+        int pid = parent[i];
+        m_nodes[nid].parent = pid;
+        m_nodes[pid].children.push_back(nid);
+        memcpy(m_nodes[nid].descriptor, ndesc + (size_t)i * 32, 32);
+        m_nodes[nid].weight = nweight[i];
+        if (is_leaf[i] > 0) m_nodes[nid].word_id = nwords++;
+    }
+    std::map<unsigned int, double> v;                       /* BowVector */
+    std::map<unsigned int, std::vector<unsigned int> > fv;  /* FeatureVector */
+    const bool must = scoring != 5;                         /* DotProductScoring::mustNormalize is false */
+    const int norm_l2 = scoring == 1;
+    const int m_L = L;
+    for (int i_feature = 0; i_feature < nf; i_feature++) {
+        const uint8_t *feature = feats + (size_t)i_feature * 32;
+        /* transform(feature, word_id, weight, &nid, levelsup) */
+        unsigned int nid = 0;
+        int final_id = 0;
+        const int nid_level = m_L - levelsup;
+        if (nid_level <= 0) nid = 0;
+        int current_level = 0;
+        do {
+            ++current_level;
+            const std::vector<int> &nodes = m_nodes[final_id].children;
+            final_id = nodes[0];
+            double best_d = orc_descriptor_distance(feature, m_nodes[final_id].descriptor);
+            for (size_t c = 1; c < nodes.size(); ++c) {
+                int id = nodes[c];
+                double d = orc_descriptor_distance(feature, m_nodes[id].descriptor);
+                if (d < best_d) { best_d = d; final_id = id; }
+            }
+            if (current_level == nid_level) nid = final_id;
+        } while (!m_nodes[final_id].isLeaf());
+        const unsigned int id = m_nodes[final_id].word_id;
+        const double w = m_nodes[final_id].weight;
+        if (w > 0) {
+            std::map<unsigned int, double>::iterator vit = v.lower_bound(id);
+            if (weighting == 0 || weighting == 1) {   /* TF_IDF, TF: addWeight */
+                if (vit != v.end() && !(v.key_comp()(id, vit->first))) vit->second += w;
+                else v.insert(vit, std::map<unsigned int, double>::value_type(id, w));
+            } else {                                   /* IDF, BINARY: addIfNotExist */
+                if (vit == v.end() || (v.key_comp()(id, vit->first))) v.insert(vit, std::map<unsigned int, double>::value_type(id, w));
+            }
+            fv[nid].push_back(i_feature);             /* addFeature */
+        }
+    }
+    if ((weighting == 0 || weighting == 1) && !v.empty() && !must) {
+        const double nd = v.size();
+        for (std::map<unsigned int, double>::iterator vit = v.begin(); vit != v.end(); vit++) vit->second /= nd;
+    }
+    if (must) {   /* BowVector::normalize */
+        double norm = 0.0;
+        if (!norm_l2) { for (std::map<unsigned int, double>::iterator it = v.begin(); it != v.end(); ++it) norm += fabs(it->second); }
+        else { for (std::map<unsigned int, double>::iterator it = v.begin(); it != v.end(); ++it) norm += it->second * it->second; norm = sqrt(norm); }
+        if (norm > 0.0) for (std::map<unsigned int, double>::iterator it = v.begin(); it != v.end(); ++it) it->second /= norm;
+    }
+    int i = 0;
+    for (std::map<unsigned int, double>::iterator it = v.begin(); it != v.end(); ++it, ++i) { bow_ids[i] = it->first; bow_vals[i] = it->second; }
+    *nbow = i;
+    i = 0;
+    int off = 0;
+    for (std::map<unsigned int, std::vector<unsigned int> >::iterator it = fv.begin(); it != fv.end(); ++it, ++i) {
+        fv_nodes[i] = it->first;
+        fv_offsets[i] = off;
+        for (size_t f = 0; f < it->second.size(); f++) fv_feats[off++] = (int32_t)it->second[f];
+    }
+    fv_offsets[i] = off;
+    *nfv = i;
+    return 0;
+}

@@ -133,6 +133,14 @@ int orc_intra_matches(const uint8_t *const *desc, const int *n, int ncams,
 /* MultiCameraFrame::computeRepresentativeDesc, :530-567 (least median distance) */
 int orc_representative_desc(const uint8_t *descs, int n);
 
+/* DBoW2 TemplatedVocabulary<FORB>::transform(features, BowVector, FeatureVector, levelsup) (A.9).
+ * Vocabulary given as loadFromTextFile reads it: nodes 1..nnodes in file order (parent, leaf flag,
+ * 32-byte descriptor, weight).  Outputs as std::map iteration order (ascending ids). */
+int orc_bow_transform(int k, int L, int scoring, int weighting, const int32_t *parent, const uint8_t *is_leaf,
+                      const uint8_t *ndesc, const double *nweight, int nnodes, const uint8_t *feats, int nf,
+                      int levelsup, uint32_t *bow_ids, double *bow_vals, int *nbow, uint32_t *fv_nodes,
+                      int32_t *fv_offsets, int *nfv, int32_t *fv_feats);
+
 #ifdef __cplusplus
 }
 #endif

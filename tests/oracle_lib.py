@@ -86,6 +86,9 @@ def lib():
     L.orc_intra_matches.argtypes = [C.POINTER(C.c_void_p), _ip, C.c_int, C.c_float, C.c_float, _i32p,
                                     C.c_int, _ip]
     L.orc_representative_desc.argtypes = [C.c_void_p, C.c_int]
+    L.orc_bow_transform.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, _ip, C.c_void_p,
+                                    C.c_void_p, _ip, C.c_void_p]
     _lib = L
     return L
 
@@ -295,3 +298,58 @@ def get_matches_dist_ratio(A, iA, B, iB, ratio=0.85):
 def representative_desc(descs):
     descs = np.ascontiguousarray(descs, np.uint8).reshape(-1, 32)
     return lib().orc_representative_desc(_ptr(descs), len(descs))
+
+
+def bow_transform(vocab, feats, levelsup=4):
+    """vocab: dict(k, L, scoring, weighting, parent, is_leaf, desc, weight) in loadFromTextFile order."""
+    feats = np.ascontiguousarray(feats, np.uint8).reshape(-1, 32)
+    parent = np.ascontiguousarray(vocab["parent"], np.int32)
+    leaf = np.ascontiguousarray(vocab["is_leaf"], np.uint8)
+    nd = np.ascontiguousarray(vocab["desc"], np.uint8).reshape(-1, 32)
+    nw = np.ascontiguousarray(vocab["weight"], np.float64)
+    cap = max(len(feats), 1)
+    ids, vals = np.zeros(cap, np.uint32), np.zeros(cap, np.float64)
+    nodes, offs, ff = np.zeros(cap, np.uint32), np.zeros(cap + 1, np.int32), np.zeros(cap, np.int32)
+    nb, nf = C.c_int(), C.c_int()
+    lib().orc_bow_transform(vocab["k"], vocab["L"], vocab["scoring"], vocab["weighting"], _ptr(parent), _ptr(leaf), _ptr(nd),
+                            _ptr(nw), len(parent), _ptr(feats), len(feats), levelsup, _ptr(ids), _ptr(vals), C.byref(nb),
+                            _ptr(nodes), _ptr(offs), C.byref(nf), _ptr(ff))
+    bow = (ids[:nb.value].copy(), vals[:nb.value].copy())
+    fv = {int(nodes[i]): ff[offs[i]:offs[i + 1]].copy() for i in range(nf.value)}
+    return bow, fv
+
+
+def make_vocabulary(k=10, L=3, seed=0, scoring=0, weighting=0, ragged=True, zero_weight_frac=0.05):
+    """Synthetic vocabulary tree in loadFromTextFile order (breadth-first blocks of k children; the ORB
+    vocabulary file itself is not part of the reference repository).  With ragged=True a few inner
+    positions become leaves early, as k-means produces when a cluster cannot be split."""
+    rng = np.random.default_rng(seed)
+    parent, leaf, desc, weight = [], [], [], []
+    frontier = [(0, 0)]          # (node id, depth)
+    nid = 0
+    while frontier:
+        pid, depth = frontier.pop(0)
+        for _ in range(k):
+            nid += 1
+            is_leaf = depth + 1 == L or (ragged and depth + 1 >= 2 and rng.random() < 0.1)
+            parent.append(pid)
+            leaf.append(1 if is_leaf else 0)
+            desc.append(rng.integers(0, 256, 32, dtype=np.uint8))
+            w = 0.0
+            if is_leaf:
+                w = 0.0 if rng.random() < zero_weight_frac else float(rng.uniform(0.1, 9.0))
+                if weighting in (1, 3):
+                    w = 1.0 if w > 0 else 0.0
+            weight.append(w)
+            if not is_leaf:
+                frontier.append((nid, depth + 1))
+    return dict(k=k, L=L, scoring=scoring, weighting=weighting, parent=np.array(parent, np.int32),
+                is_leaf=np.array(leaf, np.uint8), desc=np.stack(desc), weight=np.array(weight, np.float64))
+
+
+def write_vocabulary_text(vocab, path):
+    """saveToTextFile layout: 'k L scoring weighting' then 'parent isLeaf d0..d31 weight' per node."""
+    with open(path, "w") as f:
+        f.write("%d %d %d %d\n" % (vocab["k"], vocab["L"], vocab["scoring"], vocab["weighting"]))
+        for p, l, d, w in zip(vocab["parent"], vocab["is_leaf"], vocab["desc"], vocab["weight"]):
+            f.write("%d %d %s %r\n" % (p, l, " ".join(str(int(b)) for b in d), float(w)))

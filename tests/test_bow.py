@@ -1,0 +1,113 @@
+"""DBoW2 vocabulary transform (BASELINE config #4): oracle known-answer tests (CPU) and GPU parity.
+
+DBoW2 is an un-vendored dependency of the reference and the ORB vocabulary file is not in its
+repository, so the oracle restates the published algorithm and the tests use
+synthetic vocabulary trees -- parity for this row is unpinned like the rest of the path."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+
+def tiny_vocab(weighting=0, scoring=0):
+    # k = 2, L = 2: root -> {1, 2}; 1 -> {3, 4}; 2 -> {5, 6}; words are nodes 3, 4, 5, 6 (ids 0..3)
+    z = np.zeros(32, np.uint8)
+    f = np.full(32, 255, np.uint8)
+    d1, d2 = z.copy(), f.copy()
+    d3, d4 = z.copy(), z.copy(); d4[0] = 0x0F
+    d5, d6 = f.copy(), f.copy(); d6[0] = 0xF0
+    return dict(k=2, L=2, scoring=scoring, weighting=weighting, parent=np.array([0, 0, 1, 1, 2, 2], np.int32),
+                is_leaf=np.array([0, 0, 1, 1, 1, 1], np.uint8), desc=np.stack([d1, d2, d3, d4, d5, d6]),
+                weight=np.array([0, 0, 2.0, 3.0, 0.0, 5.0]))
+
+
+def test_oracle_descent_first_child_wins_ties_and_stop_words():
+    v = tiny_vocab()
+    z = np.zeros(32, np.uint8)
+    f = np.full(32, 255, np.uint8)
+    tie = z.copy(); tie[0] = 0x03                 # 2 bits from node 3 (all zero) and 2 bits from node 4 (0x0F): first child wins
+    feats = np.stack([z, tie, f, f])               # f -> node 5 whose weight is 0: a stop word, ignored entirely
+    (ids, vals), fv = O.bow_transform(v, feats, levelsup=1)
+    assert ids.tolist() == [0] and vals.tolist() == [1.0]          # two hits on word 0, L1-normalised
+    assert list(fv) == [1] and fv[1].tolist() == [0, 1]             # node at depth L - levelsup = 1
+    g = f.copy(); g[0] = 0xF0
+    (ids, vals), fv = O.bow_transform(v, np.stack([z, g, g]), levelsup=2)
+    assert ids.tolist() == [0, 3] and np.allclose(vals, [2 / 12, 10 / 12])
+    assert list(fv) == [0]                                           # levelsup >= L: keyed by the root
+
+
+def test_oracle_weighting_and_scoring_modes():
+    z = np.zeros(32, np.uint8)
+    f = np.full(32, 255, np.uint8)
+    g = f.copy(); g[0] = 0xF0
+    feats = np.stack([z, z, g])
+    (_, tfidf), _ = O.bow_transform(tiny_vocab(0, 0), feats, 1)
+    assert np.allclose(tfidf, [4 / 9, 5 / 9])                       # TF-IDF accumulates, L1
+    (_, idf), _ = O.bow_transform(tiny_vocab(2, 0), feats, 1)
+    assert np.allclose(idf, [2 / 7, 5 / 7])                         # IDF: addIfNotExist
+    (_, l2), _ = O.bow_transform(tiny_vocab(0, 1), feats, 1)
+    assert np.allclose(l2, np.array([4, 5]) / np.sqrt(41))
+    (_, dot), _ = O.bow_transform(tiny_vocab(0, 5), feats, 1)
+    assert np.allclose(dot, [4 / 2, 5 / 2])                         # DOT_PRODUCT: no norm, divided by #words
+    (ids, vals), fv = O.bow_transform(tiny_vocab(), np.zeros((0, 32), np.uint8), 1)
+    assert len(ids) == 0 and fv == {}
+
+
+def test_text_loader_round_trip_matches_arrays(tmp_path):
+    from importlib import import_module
+    pkg = import_module("mc-slam_amd")
+    if pkg.device_count() < 1:
+        pytest.skip("vocabulary objects live on the device")
+    v = O.make_vocabulary(4, 3, seed=3)
+    path = os.path.join(tmp_path, "voc.txt")
+    O.write_vocabulary_text(v, path)
+    voc = pkg.ORBVocabulary()
+    assert voc.loadFromTextFile(path)
+    assert voc.info()["nodes"] == len(v["parent"]) + 1 and voc.info()["words"] == int(v["is_leaf"].sum())
+    assert not pkg.ORBVocabulary().loadFromTextFile(os.path.join(tmp_path, "missing.txt"))
+
+
+def _same(bow_fv_a, bow_fv_b):
+    (ia, va), fa = bow_fv_a
+    (ib, vb), fb = bow_fv_b
+    assert np.array_equal(ia, ib)
+    assert np.array_equal(va, vb), "BowVector values differ (max %g)" % np.abs(va - vb).max()   # same sums in the same order
+    assert sorted(fa) == sorted(fb)
+    for k in fa:
+        assert np.array_equal(fa[k], fb[k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,L,weighting,scoring,levelsup", [(10, 3, 0, 0, 2), (10, 4, 0, 0, 4), (5, 5, 1, 1, 3), (3, 6, 2, 0, 4),
+                                                            (10, 3, 3, 5, 1), (7, 2, 0, 0, 4)])
+def test_transform_matches_oracle(k, L, weighting, scoring, levelsup):
+    import mcorb
+    v = O.make_vocabulary(k, L, seed=k * 10 + L, scoring=scoring, weighting=weighting)
+    voc = mcorb.ORBVocabulary().create(**v)
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 37, 2000):
+        feats = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        if n > 10:                                   # exact node descriptors: distance 0, and ties between siblings
+            feats[:5] = v["desc"][rng.integers(0, len(v["desc"]), 5)]
+        _same(O.bow_transform(v, feats, levelsup), voc.transform(feats, levelsup))
+
+
+@pytest.mark.gpu
+def test_transform_of_rig_descriptors_in_place():
+    """BoW vectors of the extracted cameras, computed from the descriptors still resident in HBM
+    (MultiCameraFrame::extractFeatureSingle's transform call, MultiCameraFrame.cpp:257)."""
+    import mcorb
+    C, W, H, N = 2, 640, 480, 1000
+    rig = mcorb.Rig(C, W, H, 1, 1, nfeatures=N)
+    rig.upload([mcorb.synth_rig_frame(0, C, c, W, H) for c in range(C)])
+    rig.extract(C)
+    v = O.make_vocabulary(10, 4, seed=7)
+    voc = mcorb.ORBVocabulary().create(**v)
+    for c in range(C):
+        d = rig.features(c)[2]
+        got = voc.transform_rig_image(rig, c, levelsup=4)
+        _same(O.bow_transform(v, d, 4), got)
+        assert abs(got[0][1].sum() - 1.0) < 1e-12 and sum(len(x) for x in got[1].values()) <= len(d)
+    rig.close()
