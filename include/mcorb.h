@@ -236,6 +236,15 @@ int mcorb_rig_transform_image(mcorb_rig *r, int slot, int m, mcorb_vocab *v, int
                               double *bow_vals, int bow_cap, int *nbow, uint32_t *fv_nodes, int32_t *fv_offsets,
                               int fv_cap, int *nfv, int32_t *fv_feats, int feat_cap);
 
+/* computeIntraMatches(matches, words_), the BoW-guided live variant (MultiCameraFrame.cpp:586-943,
+ * FrontEnd.cpp:1009) for one extracted rig frame of a slot: vocabulary descent and the per-node
+ * best / second-best distance table on the GPU, the reference's serial track bookkeeping on the host.
+ * tracks: ntracks x ncams matchIndex rows (-1 absent); n_rays per track; words: node id pushed to
+ * words_ for every accepted feature.  max_neighbor_ratio = ORBextractor::max_neighbor_ratio (0.85). */
+int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_vocab *v, int levelsup, double max_neighbor_ratio,
+                        int32_t *tracks, int32_t *n_rays, int cap_tracks, int *ntracks_out, uint32_t *words,
+                        int cap_words, int *nwords_out);
+
 /* ------------------------------------------------------------------------- */
 /* Host stages exposed for the CPU test-suite (no device needed)              */
 /* ------------------------------------------------------------------------- */

@@ -393,6 +393,17 @@ class ORBVocabulary:
         d = _u8(features).reshape(-1, 32)
         return self._call(self.L_.mcorb_vocab_transform, (self.h, d.ctypes.data, len(d)), len(d), levelsup)
 
+    def match_rig_frame(self, rig, frame=0, slot=0, levelsup=4, max_neighbor_ratio=0.85):
+        """computeIntraMatches(matches, words_) (MultiCameraFrame.cpp:586-943): (tracks, n_rays, words)."""
+        cap = rig.kcap * rig.ncams
+        tr = np.full((cap, rig.ncams), -1, np.int32)
+        nr = np.zeros(cap, np.int32)
+        words = np.zeros(cap, np.uint32)
+        nt, nw = C.c_int(), C.c_int()
+        _lib.check(self.L_.mcorb_rig_match_bow(rig.h_rig, slot, frame, self.h, levelsup, max_neighbor_ratio, tr.ctypes.data,
+                                               nr.ctypes.data, cap, C.byref(nt), words.ctypes.data, cap, C.byref(nw)))
+        return tr[:nt.value].copy(), nr[:nt.value].copy(), words[:nw.value].copy()
+
     def transform_rig_image(self, rig, m, slot=0, levelsup=4):
         """transform() of image m's descriptors straight from the rig's HBM buffers (MultiCameraFrame.cpp:257)."""
         n = rig.L.mcorb_rig_num_keypoints(rig.h_rig, slot, m)
@@ -455,6 +466,16 @@ class MultiCameraFrame:
         self._ensure_match(dist_thresh, neigh_ratio)
         i1, i2 = self.rig.pair_matches(0, img1_ind, img2_ind)
         return i1, i2, self.image_kps_undist[img1_ind][i1], self.image_kps_undist[img2_ind][i2]
+
+    def computeIntraMatchesBoW(self, vocabulary, words_=None, levelsup=4):
+        """computeIntraMatches(matches, words_) (MultiCameraFrame.cpp:586-943), the call FrontEnd.cpp:1009 makes."""
+        tr, nr, words = vocabulary.match_rig_frame(self.rig, 0, levelsup=levelsup)
+        if words_ is not None:
+            words_.extend(int(w) for w in words)
+        out = [IntraMatch(row) for row in tr]
+        for m, n in zip(out, nr):
+            m.n_rays = int(n)
+        return out
 
     def computeIntraMatches(self, old=False, dist_thresh=75.0, ratio=0.85):
         """computeIntraMatches(matches, old=false) (MultiCameraFrame.cpp:1100-1288)."""

@@ -307,3 +307,216 @@ extern "C" int mcorb_rig_transform_image(mcorb_rig *r, int slot, int m, mcorb_vo
     return transform_device(v, s->d_desc + (size_t)m * r->rig.geom.kcap * 32, n, levelsup, s->st, bow_ids, bow_vals, bow_cap, nbow,
                             fv_nodes, fv_offsets, fv_cap, nfv, fv_feats, feat_cap);
 }
+
+// ---------------------------------------------------------------------------
+// computeIntraMatches(matches, words_): the BoW-guided live variant (MultiCameraFrame.cpp:586-943).
+// GPU: vocabulary descent of every camera's descriptors + the per-node best/second-best table
+// (k_bow_best2).  Host: the reference's serial iteration over common nodes and its track
+// bookkeeping (new track / extend / merge into an existing one / override), replayed on that table.
+// ---------------------------------------------------------------------------
+namespace {
+struct BowTrack { std::vector<int> matchIndex; int n_rays; };
+}
+
+extern "C" int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_vocab *v, int levelsup, double max_neighbor_ratio,
+                                   int32_t *tracks, int32_t *n_rays, int cap_tracks, int *ntracks_out, uint32_t *words,
+                                   int cap_words, int *nwords_out)
+{
+    if (ntracks_out) *ntracks_out = 0;
+    if (nwords_out) *nwords_out = 0;
+    if (!r || !v || slot < 0 || slot >= (int)r->rig.slots.size() || !tracks) { set_error("match_bow: bad argument"); return MCORB_E_ARG; }
+    Rig &R = r->rig;
+    Slot *s = R.slots[slot];
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        if (s->busy) { set_error("slot busy"); return MCORB_E_STATE; }
+    }
+    const int C = R.ncams, kcap = R.geom.kcap;
+    if (frame < 0 || (frame + 1) * C > s->nimg_done) { set_error("match_bow: frame not extracted"); return MCORB_E_STATE; }
+    if (v->device != R.device) { set_error("vocabulary lives on another device"); return MCORB_E_ARG; }
+    HIPCHK(hipSetDevice(R.device));
+    const int TH_LOW = 75;   // ORBextractor.h:27
+
+    // 1. FeatureVector of every camera (transform(..., levelsup), MultiCameraFrame.cpp:257)
+    std::vector<std::map<uint32_t, std::vector<int32_t>>> fvs(C);
+    std::vector<int> nfeat(C);
+    for (int c = 0; c < C; c++) {
+        const int m = frame * C + c, n = s->h_nsel[m];
+        nfeat[c] = n;
+        int st = ensure_scratch(v, std::max(n, 1));
+        if (st != MCORB_OK) return st;
+        if (n > 0) {
+            launch_bow_descend(s->st, s->d_desc + (size_t)m * kcap * 32, n, v->d_child_start, v->d_child_count, v->d_child_desc,
+                               v->d_child_id, v->L - levelsup, v->d_out);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(v->h_out, v->d_out, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost, s->st));
+            HIPCHK(hipStreamSynchronize(s->st));
+            std::map<uint32_t, double> bow;
+            assemble(v, v->h_out, n, bow, fvs[c]);
+        }
+        if (fvs[c].empty()) return MCORB_OK;   // the reference returns with no matches (:602-603)
+    }
+
+    // 2. node slots (distinct node ids over all cameras) and per-(slot, camera) feature ranges
+    std::map<uint32_t, int> slot_id;
+    for (int c = 0; c < C; c++)
+        for (auto &e : fvs[c]) slot_id.emplace(e.first, 0);
+    int ns = 0;
+    for (auto &e : slot_id) e.second = ns++;
+    std::vector<int> slot_of((size_t)C * kcap, -1), node_feats((size_t)C * kcap, 0), sets(C);
+    std::vector<int2> node_range((size_t)ns * C, int2{0, 0});
+    std::vector<float> yv((size_t)C * kcap, 0.f);
+    for (int c = 0; c < C; c++) {
+        sets[c] = frame * C + c;
+        int pos = 0;
+        for (auto &e : fvs[c]) {
+            const int sl = slot_id[e.first];
+            node_range[(size_t)sl * C + c] = int2{pos, (int)e.second.size()};
+            for (int32_t f : e.second) { node_feats[(size_t)c * kcap + pos++] = f; slot_of[(size_t)c * kcap + f] = sl; }
+        }
+        const std::vector<mcorb_keypoint> &K = s->kps[frame * C + c];
+        for (size_t k = 0; k < K.size(); k++) yv[(size_t)c * kcap + k] = K[k].y;   // image_kps_undist[c][k].pt.y
+    }
+
+    // 3. best / second-best table on the GPU
+    int *d_i = nullptr;
+    float *d_y = nullptr;
+    int2 *d_rg = nullptr;
+    int4 *d_tab = nullptr;
+    const size_t n_i = (size_t)C * kcap * 2 + C * 2, tab_n = (size_t)C * kcap * C;
+    HIPCHK(hipMalloc((void **)&d_i, n_i * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&d_y, yv.size() * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&d_rg, std::max<size_t>(node_range.size(), 1) * sizeof(int2)));
+    HIPCHK(hipMalloc((void **)&d_tab, tab_n * sizeof(int4)));
+    int *d_slot_of = d_i, *d_node_feats = d_i + (size_t)C * kcap, *d_sets = d_i + (size_t)C * kcap * 2, *d_nfeat = d_sets + C;
+    std::vector<int4> tab(tab_n);
+    int rc = MCORB_OK;
+    do {
+#define CK(x) if ((x) != hipSuccess) { set_error(#x); rc = MCORB_E_HIP; break; }
+        CK(hipMemcpyAsync(d_slot_of, slot_of.data(), slot_of.size() * sizeof(int), hipMemcpyHostToDevice, s->st));
+        CK(hipMemcpyAsync(d_node_feats, node_feats.data(), node_feats.size() * sizeof(int), hipMemcpyHostToDevice, s->st));
+        CK(hipMemcpyAsync(d_sets, sets.data(), C * sizeof(int), hipMemcpyHostToDevice, s->st));
+        CK(hipMemcpyAsync(d_nfeat, nfeat.data(), C * sizeof(int), hipMemcpyHostToDevice, s->st));
+        CK(hipMemcpyAsync(d_y, yv.data(), yv.size() * sizeof(float), hipMemcpyHostToDevice, s->st));
+        if (!node_range.empty()) CK(hipMemcpyAsync(d_rg, node_range.data(), node_range.size() * sizeof(int2), hipMemcpyHostToDevice, s->st));
+        launch_bow_best2(s->st, s->d_desc, d_sets, kcap, C, d_y, d_slot_of, d_rg, d_node_feats, d_nfeat, d_tab);
+        CK(hipGetLastError());
+        CK(hipMemcpyAsync(tab.data(), d_tab, tab_n * sizeof(int4), hipMemcpyDeviceToHost, s->st));
+        CK(hipStreamSynchronize(s->st));
+#undef CK
+    } while (0);
+    (void)hipFree(d_i); (void)hipFree(d_y); (void)hipFree(d_rg); (void)hipFree(d_tab);
+    if (rc != MCORB_OK) return rc;
+
+    // 4. the reference's serial walk over common nodes (:647-929), reading best/second-best from the table
+    typedef std::map<uint32_t, std::vector<int32_t>>::const_iterator It;
+    std::vector<It> it(C), last(C);
+    for (int c = 0; c < C; c++) { it[c] = fvs[c].begin(); last[c] = std::prev(fvs[c].end()); }
+    std::vector<BowTrack> matches;
+    std::vector<uint32_t> words_;
+    int intraMatchInd = 0;
+    const uint8_t *hd = s->h_desc;
+    auto dist = [&](int ca, int fa, int cb, int fb) {
+        return mcorb_hamming256(hd + ((size_t)(frame * C + ca) * kcap + fa) * 32, hd + ((size_t)(frame * C + cb) * kcap + fb) * 32);
+    };
+    for (;;) {
+        bool end = true;   // checkItersEnd (:569-575)
+        for (int c = 0; c < C; c++) end = end && it[c]->first >= last[c]->first;
+        if (end) break;
+        uint32_t min_val = 0x7ffffffeu;
+        std::vector<int> selected;
+        for (int c = 0; c < C; c++) {
+            const uint32_t w = it[c] == last[c] ? 0x7fffffffu : it[c]->first;
+            if (w < min_val) { min_val = w; selected.clear(); selected.push_back(c); }
+            else if (w == min_val) selected.push_back(c);
+        }
+        std::vector<std::vector<int>> matchedFlags(selected.size());
+        for (size_t i = 0; i < selected.size(); i++) matchedFlags[i].assign(it[selected[i]]->second.size(), -1);
+        if (selected.size() >= 2) {
+            for (int i = 0; i < (int)selected.size() - 1; i++) {
+                const int cam1 = selected[i];
+                const std::vector<int32_t> &feat_cam1 = it[cam1]->second;
+                for (int a = 0; a < (int)feat_cam1.size(); a++) {
+                    bool foundMatch = false;
+                    if (matchedFlags[i][a] != -1) continue;
+                    BowTrack temp;
+                    temp.matchIndex.assign(C, -1);
+                    temp.matchIndex[cam1] = feat_cam1[a];
+                    temp.n_rays = 1;
+                    matches.push_back(temp);
+                    matchedFlags[i][a] = intraMatchInd;
+                    bool updateOnce = true;
+                    for (int j = i + 1; j < (int)selected.size(); j++) {
+                        const int cam2 = selected[j];
+                        const std::vector<int32_t> &feat_cam2 = it[cam2]->second;
+                        const int4 t = tab[((size_t)cam1 * kcap + feat_cam1[a]) * C + cam2];
+                        const int best_j_now = t.x;
+                        const double best_dist_1 = t.x < 0 ? 1e9 : (double)t.y;
+                        const double best_dist_2 = t.z == 0x7fffffff ? 1e9 : (double)t.z;
+                        if (best_dist_1 <= TH_LOW && best_dist_1 / best_dist_2 <= max_neighbor_ratio) {
+                            const int existing = matchedFlags[j][best_j_now];
+                            if (existing == intraMatchInd) continue;
+                            if (existing == -1) {
+                                matches[intraMatchInd].matchIndex[cam2] = feat_cam2[best_j_now];
+                                matches[intraMatchInd].n_rays++;
+                                matchedFlags[j][best_j_now] = intraMatchInd;
+                                foundMatch = true;
+                            } else {
+                                const int old_cam1 = matches[existing].matchIndex[cam1];
+                                if (old_cam1 == -1) {
+                                    if (updateOnce) updateOnce = false;
+                                    else continue;
+                                    bool update_match = true;
+                                    std::vector<int> tmp = matches[existing].matchIndex;
+                                    int inc = 0;
+                                    for (int tt = 0; tt < C; tt++) {
+                                        if (matches[intraMatchInd].matchIndex[tt] != -1) {
+                                            if (matches[existing].matchIndex[tt] != -1) { update_match = false; break; }
+                                            tmp[tt] = matches[intraMatchInd].matchIndex[tt];
+                                            inc++;
+                                        }
+                                    }
+                                    if (update_match) {
+                                        matches[existing].matchIndex = tmp;
+                                        matches[existing].n_rays += inc;
+                                        matchedFlags[i][a] = existing;
+                                        intraMatchInd = existing;
+                                        foundMatch = true;
+                                        matches.pop_back();
+                                    }
+                                    continue;
+                                }
+                                const double d = dist(cam1, old_cam1, cam2, feat_cam2[best_j_now]);
+                                if (best_dist_1 < d) {
+                                    matches[existing].matchIndex[cam2] = -1;
+                                    matches[existing].n_rays--;
+                                    matches[intraMatchInd].matchIndex[cam2] = feat_cam2[best_j_now];
+                                    matches[intraMatchInd].n_rays++;
+                                    matchedFlags[j][best_j_now] = intraMatchInd;
+                                    foundMatch = true;
+                                }
+                            }
+                        }
+                    }
+                    if (foundMatch) {
+                        words_.push_back(it[selected[0]]->first);
+                        intraMatchInd = (int)matches.size();
+                    } else {
+                        matches.pop_back();
+                        matchedFlags[i][a] = -1;
+                    }
+                }
+            }
+        }
+        for (int c : selected) ++it[c];
+    }
+    if (ntracks_out) *ntracks_out = (int)matches.size();
+    if (nwords_out) *nwords_out = (int)words_.size();
+    if ((int)matches.size() > cap_tracks || (words && (int)words_.size() > cap_words)) { set_error("match_bow: output too small"); return MCORB_E_CAP; }
+    for (size_t m = 0; m < matches.size(); m++) {
+        for (int c = 0; c < C; c++) tracks[m * C + c] = matches[m].matchIndex[c];
+        if (n_rays) n_rays[m] = matches[m].n_rays;
+    }
+    if (words) for (size_t w = 0; w < words_.size(); w++) words[w] = words_[w];
+    return MCORB_OK;
+}

@@ -32,6 +32,8 @@ void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, co
 void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const int2 *pairs, int npairs, int kcap,
                  uint2 *part, float dist_thresh, float ratio, KnnRow *out, hipEvent_t ev_mid);
 
+void launch_bow_best2(hipStream_t st, const uint8_t *desc, const int *sets, int kcap, int ncams, const float *yv,
+                      const int *slot_of, const int2 *node_range, const int *node_feats, const int *nfeat, int4 *out);
 void launch_bow_descend(hipStream_t st, const uint8_t *desc, int n, const int *child_start, const int *child_count,
                         const void *child_desc, const int *child_id, int nid_level, int2 *out);
 

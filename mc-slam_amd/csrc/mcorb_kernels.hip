@@ -981,6 +981,38 @@ __global__ __launch_bounds__(256) void k_bow_descend(const uint8_t *__restrict__
 }
 
 // ---------------------------------------------------------------------------
+// BoW-guided intra-rig matching, the data-parallel half (MultiCameraFrame::computeIntraMatches(matches,
+// words_), MultiCameraFrame.cpp:708-745): for feature a of camera c1 and every camera c2 > c1, the best
+// and second-best Hamming distance among c2's features that fell into the same vocabulary node, skipping
+// candidates whose row differs by 50 px or more; strict '<' so the first minimum wins.  The serial
+// track bookkeeping that consumes this table stays on the host.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_bow_best2(const uint8_t *__restrict__ desc, const int *__restrict__ sets, int kcap, int ncams,
+                                                   const float *__restrict__ yv, const int *__restrict__ slot_of,
+                                                   const int2 *__restrict__ node_range, const int *__restrict__ node_feats,
+                                                   const int *__restrict__ nfeat, int4 *__restrict__ out)
+{
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    const int c1 = blockIdx.y, c2 = blockIdx.z;
+    if (c2 <= c1 || a >= nfeat[c1]) return;
+    int4 r = int4{-1, 0x7fffffff, 0x7fffffff, 0};
+    const int slot = slot_of[(size_t)c1 * kcap + a];
+    if (slot >= 0) {
+        const int2 rg = node_range[(size_t)slot * ncams + c2];
+        const ulonglong4 q = *reinterpret_cast<const ulonglong4 *>(desc + ((size_t)sets[c1] * kcap + a) * 32);
+        const float y1 = yv[(size_t)c1 * kcap + a];
+        for (int j = 0; j < rg.y; j++) {
+            const int b = node_feats[(size_t)c2 * kcap + rg.x + j];
+            if (fabsf(__fsub_rn(y1, yv[(size_t)c2 * kcap + b])) >= 50.f) continue;
+            const int d = (int)hamming256(q, *reinterpret_cast<const ulonglong4 *>(desc + ((size_t)sets[c2] * kcap + b) * 32));
+            if (d < r.y) { r.x = j; r.z = r.y; r.y = d; }
+            else if (d < r.z) r.z = d;
+        }
+    }
+    out[((size_t)c1 * kcap + a) * ncams + c2] = r;
+}
+
+// ---------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------
 hipError_t upload_umax(const int umax[16]) { return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax, 16 * sizeof(int)); }
@@ -1058,6 +1090,13 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
     if (ev_mid) (void)hipEventRecord(ev_mid, st);
     dim3 g2((kcap + 255) / 256, npairs);
     hipLaunchKernelGGL(k_knn2_finalize, g2, dim3(256), 0, st, part, counts, pairs, kcap, nchunks, dist_thresh, ratio, out);
+}
+
+void launch_bow_best2(hipStream_t st, const uint8_t *desc, const int *sets, int kcap, int ncams, const float *yv,
+                      const int *slot_of, const int2 *node_range, const int *node_feats, const int *nfeat, int4 *out)
+{
+    dim3 grid((kcap + 255) / 256, ncams, ncams);
+    hipLaunchKernelGGL(k_bow_best2, grid, dim3(256), 0, st, desc, sets, kcap, ncams, yv, slot_of, node_range, node_feats, nfeat, out);
 }
 
 void launch_bow_descend(hipStream_t st, const uint8_t *desc, int n, const int *child_start, const int *child_count,

@@ -1197,3 +1197,164 @@ extern "C" int orc_bow_transform(int k, int L, int scoring, int weighting, const
     *nfv = i;
     return 0;
 }
+
+/* ------------------------------------------------------------------------- */
+/* MultiCameraFrame::computeIntraMatches(matches, words_) -- the BoW-guided (live) variant,       */
+/* MCSlam/src/MultiCameraFrame.cpp:586-943, with checkItersEnd (:569-575).  FeatureVectors are     */
+/* passed as arrays (node ids ascending, offsets, feature indices) and rebuilt as std::map.        */
+/* matchIndex is widened from array<int,5> to ncams entries.                                       */
+/* ------------------------------------------------------------------------- */
+extern "C" int orc_intra_matches_bow(const uint8_t *const *desc, const float *const *kp_y, int ncams,
+                                     const uint32_t *const *fv_nodes, const int32_t *const *fv_offsets,
+                                     const int32_t *const *fv_feats, const int *nfv, double max_neighbor_ratio,
+                                     int32_t *tracks, int32_t *n_rays_out, int cap_tracks, uint32_t *words_out, int cap_words,
+                                     int *nwords_out)
+{
+    typedef std::map<unsigned int, std::vector<unsigned int> > FeatureVector;
+    const int TH_LOW = 75;
+    const int num_cams_ = ncams;
+    struct IM { std::vector<int> matchIndex; int n_rays; };
+    std::vector<IM> matches;
+    std::vector<unsigned int> words_;
+    if (nwords_out) *nwords_out = 0;
+
+    std::vector<FeatureVector> featVecs(num_cams_);
+    std::vector<FeatureVector::const_iterator> featVecIters(num_cams_), featVecEnds(num_cams_);
+    for (int i = 0; i < num_cams_; i++) {
+        for (int k = 0; k < nfv[i]; k++) {
+            std::vector<unsigned int> &v = featVecs[i][fv_nodes[i][k]];
+            for (int f = fv_offsets[i][k]; f < fv_offsets[i][k + 1]; f++) v.push_back((unsigned int)fv_feats[i][f]);
+        }
+        if (featVecs[i].size() == 0) return 0;                     /* :602-603 */
+        featVecIters[i] = featVecs[i].begin();
+        featVecEnds[i] = std::prev(featVecs[i].end());             /* :606 */
+    }
+    int intraMatchInd = 0;
+    for (;;) {
+        /* checkItersEnd, :569-575 */
+        bool res = true;
+        for (int i = 0; i < num_cams_; i++) res = res && featVecIters[i]->first >= featVecEnds[i]->first;
+        if (res) break;
+
+        std::vector<unsigned int> wordIds;
+        for (int i = 0; i < num_cams_; i++) {
+            if (featVecIters[i] == featVecEnds[i]) wordIds.push_back(INT_MAX);
+            else wordIds.push_back(featVecIters[i]->first);
+        }
+        int min_val = INT_MAX - 1;
+        int second_min_val = INT_MAX - 1;
+        std::vector<int> selected_cams;
+        std::vector<std::vector<int> > matchedFlags;
+        for (int i = 0; i < num_cams_; i++) {
+            if (wordIds[i] < (unsigned int)min_val) {
+                second_min_val = min_val;
+                min_val = wordIds[i];
+                selected_cams.clear();
+                matchedFlags.clear();
+                selected_cams.push_back(i);
+                matchedFlags.push_back(std::vector<int>(featVecIters[i]->second.size(), -1));
+            } else if (wordIds[i] == (unsigned int)min_val) {
+                selected_cams.push_back(i);
+                matchedFlags.push_back(std::vector<int>(featVecIters[i]->second.size(), -1));
+            } else if (wordIds[i] < (unsigned int)second_min_val)
+                second_min_val = wordIds[i];
+        }
+        if (selected_cams.size() >= 2) {
+            for (int i = 0; i < (int)selected_cams.size() - 1; i++) {
+                int cam1 = selected_cams[i];
+                std::vector<unsigned int> feat_cam1 = featVecIters[cam1]->second;
+                for (int cam1_feat_ind = 0; cam1_feat_ind < (int)feat_cam1.size(); cam1_feat_ind++) {
+                    bool foundMatch = false;
+                    int cam1_existing_intramatch = matchedFlags[i][cam1_feat_ind];
+                    if (cam1_existing_intramatch != -1) continue;
+                    IM temp;
+                    temp.matchIndex.assign(num_cams_, -1);
+                    temp.matchIndex[cam1] = feat_cam1[cam1_feat_ind];
+                    temp.n_rays = 1;
+                    matches.push_back(temp);
+                    matchedFlags[i][cam1_feat_ind] = intraMatchInd;
+                    bool updateOnce = true;
+                    for (int j = i + 1; j < (int)selected_cams.size(); j++) {
+                        int cam2 = selected_cams[j];
+                        std::vector<unsigned int> feat_cam2 = featVecIters[cam2]->second;
+                        int best_j_now = -1;
+                        double best_dist_1 = 1e9;
+                        double best_dist_2 = 1e9;
+                        for (int cam2_feat_ind = 0; cam2_feat_ind < (int)feat_cam2.size(); cam2_feat_ind++) {
+                            if (fabsf(kp_y[cam1][feat_cam1[cam1_feat_ind]] - kp_y[cam2][feat_cam2[cam2_feat_ind]]) >= 50) continue;
+                            double d = orc_descriptor_distance(desc[cam1] + (size_t)feat_cam1[cam1_feat_ind] * 32,
+                                                               desc[cam2] + (size_t)feat_cam2[cam2_feat_ind] * 32);
+                            if (d < best_dist_1) {
+                                best_j_now = cam2_feat_ind;
+                                best_dist_2 = best_dist_1;
+                                best_dist_1 = d;
+                            } else if (d < best_dist_2) {
+                                best_dist_2 = d;
+                            }
+                        }
+                        if (best_dist_1 <= TH_LOW && best_dist_1 / best_dist_2 <= max_neighbor_ratio) {
+                            int existing_intramatch = matchedFlags[j][best_j_now];
+                            if (existing_intramatch == intraMatchInd) continue;
+                            if (existing_intramatch == -1) {
+                                matches[intraMatchInd].matchIndex[cam2] = feat_cam2[best_j_now];
+                                matches[intraMatchInd].n_rays++;
+                                matchedFlags[j][best_j_now] = intraMatchInd;
+                                foundMatch = true;
+                            } else {
+                                int old_cam1_match_ind = matches[existing_intramatch].matchIndex[cam1];
+                                if (old_cam1_match_ind == -1) {
+                                    if (updateOnce) updateOnce = false;
+                                    else continue;
+                                    bool update_match = true;
+                                    std::vector<int> tempmatchIndex = matches[existing_intramatch].matchIndex;
+                                    int tmp_nrays_inc = 0;
+                                    for (int tt1 = 0; tt1 < num_cams_; tt1++) {
+                                        if (matches[intraMatchInd].matchIndex[tt1] != -1) {
+                                            if (matches[existing_intramatch].matchIndex[tt1] != -1) { update_match = false; break; }
+                                            tempmatchIndex[tt1] = matches[intraMatchInd].matchIndex[tt1];
+                                            tmp_nrays_inc++;
+                                        }
+                                    }
+                                    if (update_match) {
+                                        matches[existing_intramatch].matchIndex = tempmatchIndex;
+                                        matches[existing_intramatch].n_rays += tmp_nrays_inc;
+                                        matchedFlags[i][cam1_feat_ind] = existing_intramatch;
+                                        intraMatchInd = existing_intramatch;
+                                        foundMatch = true;
+                                        matches.pop_back();
+                                    }
+                                    continue;
+                                }
+                                double d = orc_descriptor_distance(desc[cam1] + (size_t)old_cam1_match_ind * 32,
+                                                                   desc[cam2] + (size_t)feat_cam2[best_j_now] * 32);
+                                if (best_dist_1 < d) {
+                                    matches[existing_intramatch].matchIndex[cam2] = -1;
+                                    matches[existing_intramatch].n_rays--;
+                                    matches[intraMatchInd].matchIndex[cam2] = feat_cam2[best_j_now];
+                                    matches[intraMatchInd].n_rays++;
+                                    matchedFlags[j][best_j_now] = intraMatchInd;
+                                    foundMatch = true;
+                                }
+                            }
+                        }
+                    }
+                    if (foundMatch) {
+                        words_.push_back(featVecIters[selected_cams[0]]->first);
+                        intraMatchInd = (int)matches.size();
+                    } else {
+                        matches.pop_back();
+                        matchedFlags[i][cam1_feat_ind] = -1;
+                    }
+                }
+            }
+        }
+        for (int s_word = 0; s_word < (int)selected_cams.size(); s_word++) ++featVecIters[selected_cams[s_word]];
+    }
+    for (size_t m = 0; m < matches.size() && (int)m < cap_tracks; m++) {
+        for (int c = 0; c < ncams; c++) tracks[m * ncams + c] = matches[m].matchIndex[c];
+        if (n_rays_out) n_rays_out[m] = matches[m].n_rays;
+    }
+    for (size_t w = 0; w < words_.size() && (int)w < cap_words; w++) words_out[w] = words_[w];
+    if (nwords_out) *nwords_out = (int)words_.size();
+    return (int)matches.size();
+}

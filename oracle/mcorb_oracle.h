@@ -141,6 +141,15 @@ int orc_bow_transform(int k, int L, int scoring, int weighting, const int32_t *p
                       int levelsup, uint32_t *bow_ids, double *bow_vals, int *nbow, uint32_t *fv_nodes,
                       int32_t *fv_offsets, int *nfv, int32_t *fv_feats);
 
+/* MultiCameraFrame::computeIntraMatches(matches, words_), the BoW-guided live variant
+ * (MultiCameraFrame.cpp:586-943).  Per camera: descriptors, keypoint y (image_kps_undist[].pt.y) and the
+ * FeatureVector as arrays.  tracks: ntracks x ncams; n_rays per track; words_: node id per accepted feature. */
+int orc_intra_matches_bow(const uint8_t *const *desc, const float *const *kp_y, int ncams,
+                          const uint32_t *const *fv_nodes, const int32_t *const *fv_offsets,
+                          const int32_t *const *fv_feats, const int *nfv, double max_neighbor_ratio,
+                          int32_t *tracks, int32_t *n_rays_out, int cap_tracks, uint32_t *words_out, int cap_words,
+                          int *nwords_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,6 +86,9 @@ def lib():
     L.orc_intra_matches.argtypes = [C.POINTER(C.c_void_p), _ip, C.c_int, C.c_float, C.c_float, _i32p,
                                     C.c_int, _ip]
     L.orc_representative_desc.argtypes = [C.c_void_p, C.c_int]
+    L.orc_intra_matches_bow.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p),
+                                        C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _ip, C.c_double, C.c_void_p,
+                                        C.c_void_p, C.c_int, C.c_void_p, C.c_int, _ip]
     L.orc_bow_transform.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, _ip, C.c_void_p,
                                     C.c_void_p, _ip, C.c_void_p]
@@ -353,3 +356,28 @@ def write_vocabulary_text(vocab, path):
         f.write("%d %d %d %d\n" % (vocab["k"], vocab["L"], vocab["scoring"], vocab["weighting"]))
         for p, l, d, w in zip(vocab["parent"], vocab["is_leaf"], vocab["desc"], vocab["weight"]):
             f.write("%d %d %s %r\n" % (p, l, " ".join(str(int(b)) for b in d), float(w)))
+
+
+def intra_matches_bow(descs, kp_y, fvs, ratio=0.85):
+    """fvs: per camera FeatureVector as {node id: feature indices} (ascending iteration like std::map)."""
+    nc = len(descs)
+    descs = [np.ascontiguousarray(d, np.uint8).reshape(-1, 32) for d in descs]
+    ys = [np.ascontiguousarray(y, np.float32) for y in kp_y]
+    nodes, offs, feats = [], [], []
+    for fv in fvs:
+        ks = sorted(fv)
+        nodes.append(np.array(ks, np.uint32))
+        o = np.zeros(len(ks) + 1, np.int32)
+        o[1:] = np.cumsum([len(fv[k]) for k in ks])
+        offs.append(o)
+        feats.append(np.concatenate([np.asarray(fv[k], np.int32) for k in ks]) if ks else np.zeros(0, np.int32))
+    vp = lambda arrs: (C.c_void_p * nc)(*[_ptr(a) for a in arrs])
+    nfv = np.array([len(n) for n in nodes], np.int32)
+    cap = int(sum(len(d) for d in descs)) + 1
+    tracks = np.full((cap, nc), -1, np.int32)
+    nr = np.zeros(cap, np.int32)
+    words = np.zeros(cap, np.uint32)
+    nw = C.c_int()
+    n = lib().orc_intra_matches_bow(vp(descs), vp(ys), nc, vp(nodes), vp(offs), vp(feats), _ptr(nfv, _ip), ratio, _ptr(tracks),
+                                    _ptr(nr), cap, _ptr(words), cap, C.byref(nw))
+    return tracks[:n].copy(), nr[:n].copy(), words[:nw.value].copy()

@@ -111,3 +111,60 @@ def test_transform_of_rig_descriptors_in_place():
         _same(O.bow_transform(v, d, 4), got)
         assert abs(got[0][1].sum() - 1.0) < 1e-12 and sum(len(x) for x in got[1].values()) <= len(d)
     rig.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,k,L,levelsup", [(4, 10, 4, 2), (3, 6, 3, 1), (5, 10, 3, 2), (2, 10, 4, 3)])
+def test_bow_guided_intra_matches(C, k, L, levelsup):
+    """The reference's live intra-rig matcher (FrontEnd.cpp:1009): per-node best/second-best on the GPU,
+    serial track bookkeeping on the host, against the oracle's literal restatement."""
+    import mcorb
+    W, H, N = 640, 480, 900
+    rig = mcorb.Rig(C, W, H, 1, 1, nfeatures=N)
+    rig.upload([mcorb.synth_rig_frame(5, C, c, W, H) for c in range(C)])
+    rig.extract(C)
+    v = O.make_vocabulary(k, L, seed=11 * k + L)
+    voc = mcorb.ORBVocabulary().create(**v)
+    feats = [rig.features(c) for c in range(C)]
+    fvs = [O.bow_transform(v, f[2], levelsup)[1] for f in feats]
+    otr, onr, owords = O.intra_matches_bow([f[2] for f in feats], [f[1]["y"] for f in feats], fvs)
+    tr, nr, words = voc.match_rig_frame(rig, 0, levelsup=levelsup)
+    assert len(otr) > 50, "the synthetic rig should give real BoW-guided matches"
+    assert np.array_equal(tr, otr) and np.array_equal(nr, onr) and np.array_equal(words, owords)
+    # n_rays is NOT always the number of set cameras: after the reference merges the open track into an
+    # existing one (:795-812) a later camera can overwrite a slot and still count a ray (:765-766).
+    assert np.all(nr >= 1) and np.all((tr >= 0).sum(1) >= 1)
+    rig.close()
+
+
+def _kat_descs():
+    z = np.zeros(32, np.uint8)
+    a1 = z.copy(); a1[:10] = 0xFF                       # 80 bits away from zero
+    b0 = z.copy(); b0[31] = 0x01                        # 1 bit from zero
+    b1 = a1.copy(); b1[0] = 0xFC                        # 2 bits from a1
+    far = np.full(32, 0xAA, np.uint8)
+    return [np.stack([z, a1, far]), np.stack([b0, b1, far])]
+
+
+def test_oracle_bow_guided_matcher_known_answer():
+    """Hand-derived case for MultiCameraFrame.cpp:586-943: two cameras, node 5 holds two features per
+    camera, node 9 is the last node of both maps and is therefore never visited (:647 checkItersEnd)."""
+    descs = _kat_descs()
+    fvs = [{5: [0, 1], 9: [2]}, {5: [0, 1], 9: [2]}]
+    ys = [np.zeros(3, np.float32), np.zeros(3, np.float32)]
+    tr, nr, words = O.intra_matches_bow(descs, ys, fvs)
+    assert tr.tolist() == [[0, 0], [1, 1]] and nr.tolist() == [2, 2] and words.tolist() == [5, 5]
+    # |dy| >= 50 removes the only close candidate of feature 1 (:722-724); the other one is > TH_LOW away
+    ys[1][1] = 50.0
+    tr, nr, words = O.intra_matches_bow(descs, ys, fvs)
+    assert tr.tolist() == [[0, 0]] and words.tolist() == [5]
+    ys[1][1] = 49.5
+    assert len(O.intra_matches_bow(descs, ys, fvs)[0]) == 2
+    # ratio test: make the second-best as good as the best -> 1/1 > 0.85 rejects feature 0
+    d2 = [descs[0].copy(), descs[1].copy()]
+    d2[1][1] = d2[1][0]; d2[1][1][31] = 0x02
+    tr, _, _ = O.intra_matches_bow(d2, [np.zeros(3, np.float32)] * 2, fvs)
+    assert tr.tolist() == []
+    # a node present in one camera only is skipped; the far descriptors in the last node never match
+    fvs3 = [{5: [0, 1], 9: [2]}, {7: [0, 1], 9: [2]}]
+    assert len(O.intra_matches_bow(descs, [np.zeros(3, np.float32)] * 2, fvs3)[0]) == 0
