@@ -134,6 +134,15 @@ int mcorb_rig_get_pair_knn2(mcorb_rig *r, int slot, int frame, int cam_i, int ca
 int mcorb_rig_get_tracks(mcorb_rig *r, int slot, int frame, int32_t *tracks, int cap_tracks,
                          int *ntracks_out, int *mergeable_out);
 
+/* computeIntraMatches(matches, old=true) (MultiCameraFrame.cpp:1123-1143,1178-1207): the same merge as
+ * mcorb_rig_get_tracks with the epipolar check applied to every BruteForceMatch pair first.
+ * F: one row-major 3x3 per camera pair (i<j in the order (0,1),(0,2)..), x_j^T F x_i = 0 -- the matrix
+ * the reference builds from K_mats_/R_mats_/t_mats_ (:1126-1142); that cv::Mat algebra stays with the
+ * caller (include/mcorb_adapter.hpp does it with cv:: when OpenCV is there).  kps_undist[c]: the camera's
+ * image_kps_undist (pt and octave are read), NULL = the extracted keypoints (no distortion). */
+int mcorb_rig_get_tracks_epipolar(mcorb_rig *r, int slot, int frame, const double *F, const mcorb_keypoint *const *kps_undist,
+                                  int32_t *tracks, int cap_tracks, int *ntracks_out, int *mergeable_out);
+
 /* intermediates for stage-by-stage parity tests (device -> host copies) */
 int mcorb_rig_level_size(mcorb_rig *r, int level, int *w, int *h);
 int mcorb_rig_get_level(mcorb_rig *r, int slot, int m, int level, uint8_t *dst, int dst_stride);

@@ -233,15 +233,57 @@ public:
             kps2.push_back(image_kps[img2_ind][indices_2[k]]);
         }
     }
-    // computeIntraMatches(matches, old = false) (MultiCameraFrame.cpp:1100-1288)
+    // The per-pair fundamental matrices the old=true branch builds from camconfig_ (MultiCameraFrame.cpp:1126-1142),
+    // row-major 3x3 each, pairs in the order (0,1),(0,2)..: x_j^T F x_i = 0.
+    void setFundamental(const std::vector<double> &F_pairs)
+    {
+        if ((int)F_pairs.size() != 9 * num_cams_ * (num_cams_ - 1) / 2) throw std::runtime_error("ERROR:: need one 3x3 per camera pair");
+        F_pairs_ = F_pairs;
+    }
+#ifdef MCORB_WITH_OPENCV
+    // the same from K_mats_/R_mats_/t_mats_ (CV_64F), with the cv::Mat expressions of the reference so that the
+    // entries are the ones it computes
+    void setCalibration(const std::vector<cv::Mat> &K_mats, const std::vector<cv::Mat> &R_mats, const std::vector<cv::Mat> &t_mats)
+    {
+        F_pairs_.clear();
+        for (int i = 0; i < num_cams_ - 1; i++)
+            for (int j = i + 1; j < num_cams_; j++) {
+                cv::Mat Ti = cv::Mat::eye(4, 4, CV_64F), Tj = cv::Mat::eye(4, 4, CV_64F);
+                R_mats[i].copyTo(Ti(cv::Range(0, 3), cv::Range(0, 3)));
+                t_mats[i].copyTo(Ti(cv::Range(0, 3), cv::Range(3, 4)));
+                R_mats[j].copyTo(Tj(cv::Range(0, 3), cv::Range(0, 3)));
+                t_mats[j].copyTo(Tj(cv::Range(0, 3), cv::Range(3, 4)));
+                cv::Mat Tji = Tj * Ti.inv();
+                const double x = Tji.at<double>(0, 3), y = Tji.at<double>(1, 3), z = Tji.at<double>(2, 3);
+                cv::Mat skew = (cv::Mat_<double>(3, 3) << 0, -z, y, z, 0, -x, -y, x, 0);
+                cv::Mat F = K_mats[j].t().inv() * skew * Tji(cv::Range(0, 3), cv::Range(0, 3)) * K_mats[i].inv();
+                for (int r = 0; r < 3; r++)
+                    for (int c = 0; c < 3; c++) F_pairs_.push_back(F.at<double>(r, c));
+            }
+    }
+#endif
+    // image_kps_undist for the epipolar check; by default the extracted keypoints are used (RECTIFY=false)
+    void setUndistorted(const std::vector<std::vector<mcorb_keypoint>> &kps_undist) { image_kps_undist = kps_undist; }
+
+    // computeIntraMatches(matches, old) (MultiCameraFrame.cpp:1100-1288)
     void computeIntraMatches(std::vector<IntraMatch> &matches, bool old)
     {
-        if (old) throw std::runtime_error("epipolar gate (old=true) is not part of this path");
         ensure_match(75, 0.85f);
         const int cap = mcorb_rig_kcap(rig_) * num_cams_;
         std::vector<int32_t> tr((size_t)cap * num_cams_);
         int n = 0;
-        check(mcorb_rig_get_tracks(rig_, 0, 0, tr.data(), cap, &n, &cnt_mergable_matches), "mcorb_rig_get_tracks");
+        if (old) {
+            if (F_pairs_.empty()) throw std::runtime_error("ERROR:: computeIntraMatches(old=true) needs setFundamental/setCalibration");
+            std::vector<const mcorb_keypoint *> und;
+            if ((int)image_kps_undist.size() == num_cams_)
+                for (int c = 0; c < num_cams_; c++) {
+                    if (image_kps_undist[c].size() != image_kps[c].size()) throw std::runtime_error("ERROR:: image_kps_undist size");
+                    und.push_back(image_kps_undist[c].data());
+                }
+            check(mcorb_rig_get_tracks_epipolar(rig_, 0, 0, F_pairs_.data(), und.empty() ? nullptr : und.data(), tr.data(), cap, &n,
+                                                &cnt_mergable_matches), "mcorb_rig_get_tracks_epipolar");
+        } else
+            check(mcorb_rig_get_tracks(rig_, 0, 0, tr.data(), cap, &n, &cnt_mergable_matches), "mcorb_rig_get_tracks");
         matches.clear();
         matches.resize(n);
         for (int m = 0; m < n; m++)
@@ -251,6 +293,7 @@ public:
     int num_cams_;
     std::vector<std::vector<mcorb_keypoint>> image_kps;
     std::vector<std::vector<uint8_t>> image_descriptors;   // per camera, n x 32
+    std::vector<std::vector<mcorb_keypoint>> image_kps_undist;
     int cnt_mergable_matches = 0;
 
 private:
@@ -264,6 +307,7 @@ private:
     int w_, h_;
     bool matched_ = false;
     float thr_ = 0, ratio_ = 0;
+    std::vector<double> F_pairs_;
 };
 
 }  // namespace mcorb

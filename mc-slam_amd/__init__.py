@@ -154,6 +154,21 @@ class Rig:
         _lib.check(self.L.mcorb_rig_get_tracks(self.h_rig, slot, frame, tr.ctypes.data, cap, C.byref(n), C.byref(mg)))
         return tr[:n.value].copy(), mg.value
 
+    def tracks_epipolar(self, frame, F, kps_undist=None, slot=0):
+        """computeIntraMatches(matches, old=true): F is (npairs, 3, 3) float64 in pair order (0,1),(0,2).."""
+        npairs = self.ncams * (self.ncams - 1) // 2
+        F = np.ascontiguousarray(F, np.float64).reshape(npairs, 3, 3)
+        kp_ptrs = None
+        if kps_undist is not None:
+            keep = [np.ascontiguousarray(k, KP_DTYPE) for k in kps_undist]
+            kp_ptrs = (C.c_void_p * self.ncams)(*[k.ctypes.data for k in keep])
+        cap = self.kcap * self.ncams
+        tr = np.full((cap, self.ncams), -1, np.int32)
+        n, mg = C.c_int(), C.c_int()
+        _lib.check(self.L.mcorb_rig_get_tracks_epipolar(self.h_rig, slot, frame, F.ctypes.data, kp_ptrs, tr.ctypes.data, cap,
+                                                        C.byref(n), C.byref(mg)))
+        return tr[:n.value].copy(), mg.value
+
     # -- intermediates (parity tests) -----------------------------------------
     def level_size(self, level):
         w, h = C.c_int(), C.c_int()
@@ -410,6 +425,19 @@ class ORBVocabulary:
         return self._call(self.L_.mcorb_rig_transform_image, (rig.h_rig, slot, m, self.h), max(n, 0), levelsup)
 
 
+def fundamental_from_extrinsics(K_i, R_i, t_i, K_j, R_j, t_j):
+    """F with x_j^T F x_i = 0 from the two cameras' extrinsics, the construction of MultiCameraFrame.cpp:1126-1142."""
+    def T(R, t):
+        M = np.eye(4)
+        M[:3, :3] = np.asarray(R, np.float64)
+        M[:3, 3] = np.asarray(t, np.float64).reshape(3)
+        return M
+    Tji = T(R_j, t_j) @ np.linalg.inv(T(R_i, t_i))
+    tx, ty, tz = Tji[0, 3], Tji[1, 3], Tji[2, 3]
+    skew = np.array([[0, -tz, ty], [tz, 0, -tx], [-ty, tx, 0]], np.float64)
+    return np.linalg.inv(np.asarray(K_j, np.float64).T) @ skew @ Tji[:3, :3] @ np.linalg.inv(np.asarray(K_i, np.float64))
+
+
 class IntraMatch:
     """MultiCameraFrame.h:42-57 (matchIndex widened from 5 to ncams entries)."""
 
@@ -477,11 +505,21 @@ class MultiCameraFrame:
             m.n_rays = int(n)
         return out
 
-    def computeIntraMatches(self, old=False, dist_thresh=75.0, ratio=0.85):
-        """computeIntraMatches(matches, old=false) (MultiCameraFrame.cpp:1100-1288)."""
-        if old:
-            raise NotImplementedError("epipolar gate needs rig calibration; the live call site passes false")
+    def setCalibration(self, K_mats, R_mats, t_mats):
+        """camconfig_.K_mats_/R_mats_/t_mats_: builds the per-pair fundamental matrices of
+        MultiCameraFrame.cpp:1126-1142 (F = K_j^-T [t_ji]x R_ji K_i^-1 with T_ji = T_j0 T_i0^-1) in float64."""
+        self.F_mats = np.stack([fundamental_from_extrinsics(K_mats[i], R_mats[i], t_mats[i], K_mats[j], R_mats[j], t_mats[j])
+                                for i in range(self.num_cams_ - 1) for j in range(i + 1, self.num_cams_)])
+
+    def computeIntraMatches(self, old=False, dist_thresh=75.0, ratio=0.85, kps_undist=None):
+        """computeIntraMatches(matches, old) (MultiCameraFrame.cpp:1100-1288); old=True applies the epipolar
+        check (:1178-1207) and needs setCalibration() or F_mats."""
         self._ensure_match(dist_thresh, ratio)
-        tr, mergeable = self.rig.tracks(0)
+        if old:
+            if getattr(self, "F_mats", None) is None:
+                raise ValueError("computeIntraMatches(old=True) needs setCalibration(K, R, t) or F_mats")
+            tr, mergeable = self.rig.tracks_epipolar(0, self.F_mats, kps_undist)
+        else:
+            tr, mergeable = self.rig.tracks(0)
         self.cnt_mergable_matches = mergeable
         return [IntraMatch(row) for row in tr]

@@ -230,6 +230,27 @@ int mcorb_rig_get_tracks(mcorb_rig *r, int slot, int frame, int32_t *tracks, int
     return MCORB_OK;
 }
 
+int mcorb_rig_get_tracks_epipolar(mcorb_rig *r, int slot, int frame, const double *F, const mcorb_keypoint *const *kps_undist,
+                                  int32_t *tracks, int cap_tracks, int *ntracks_out, int *mergeable_out)
+{
+    Slot *s = get_slot(r, slot);
+    if (!s) return MCORB_E_STATE;
+    if (frame < 0 || frame >= s->nframes_done || !F) { set_error("bad frame / no fundamental matrices"); return MCORB_E_ARG; }
+    const int C = r->rig.ncams;
+    std::vector<const mcorb_keypoint *> kp(C);
+    for (int c = 0; c < C; c++) kp[c] = kps_undist && kps_undist[c] ? kps_undist[c] : s->kps[frame * C + c].data();
+    mcorb::EpipolarGate gate{F, kp.data(), r->rig.tab.sigma2};
+    std::vector<int32_t> tr;
+    int mergeable = 0;
+    r->rig.merge_tracks(*s, frame, &gate, tr, mergeable);
+    const int n = (int)(tr.size() / C);
+    if (ntracks_out) *ntracks_out = n;
+    if (mergeable_out) *mergeable_out = mergeable;
+    if (n > cap_tracks) { set_error("track buffer too small"); return MCORB_E_CAP; }
+    if (n) memcpy(tracks, tr.data(), (size_t)n * C * 4);
+    return MCORB_OK;
+}
+
 int mcorb_rig_level_size(mcorb_rig *r, int level, int *w, int *h)
 {
     if (!r || level < 0 || level >= r->rig.geom.nlevels) return MCORB_E_ARG;

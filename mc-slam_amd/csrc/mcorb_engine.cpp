@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <chrono>
 
 namespace mcorb {
@@ -724,18 +725,77 @@ int Rig::enqueue_match(Slot &s, const Job &j, bool ctrl_on_device)
     return MCORB_OK;
 }
 
-// BruteForceMatch's output lists + computeIntraMatches' track merge
-// (MultiCameraFrame.cpp:1060-1078, 1167-1268), host side, after the k-NN tables landed.
+// The epipolar check of computeIntraMatches(matches, old=true) (MultiCameraFrame.cpp:1178-1207): line in
+// image i = F^T * kp2, normalised, squared point-line distance against 3.84 * sigma2[octave].  The mixed
+// float/double arithmetic follows the reference's declared types statement by statement.
+static bool epipolar_ok(const double *F, const mcorb_keypoint &k1, const mcorb_keypoint &k2, const float *sigma2)
+{
+    float a = (float)((double)k2.x * F[0] + (double)k2.y * F[3] + F[6]);
+    float b = (float)((double)k2.x * F[1] + (double)k2.y * F[4] + F[7]);
+    float c = (float)((double)k2.x * F[2] + (double)k2.y * F[5] + F[8]);
+    float den = a * a + b * b;
+    den = den ? (float)(1. / (double)std::sqrt(den)) : (float)1.;
+    a *= den; b *= den; c *= den;
+    den = a * a + b * b;
+    const float num = a * k1.x + b * k1.y + c;
+    if (den == 0) return false;
+    const float dsqr = num * num / den;
+    const float check_thresh = (float)(3.84 * (double)sigma2[k1.octave]);
+    return dsqr < check_thresh;
+}
+
+// computeIntraMatches' track merge over the stored BruteForceMatch lists of one frame
+// (MultiCameraFrame.cpp:1167-1268); gate != nullptr adds the old=true epipolar check.
+void Rig::merge_tracks(Slot &s, int f, const EpipolarGate *gate, std::vector<int32_t> &tr, int &mergeable_out) const
+{
+    const int C = ncams;
+    tr.clear();
+    int ntr = 0, mergeable = 0;
+    std::vector<std::vector<int>> inv(C);
+    for (int c = 0; c < C; c++) inv[c].assign(s.match_counts[f * C + c], -1);
+    int pi = f * npp, pl = 0;
+    for (int a = 0; a < C - 1; a++) {
+        for (int b = a + 1; b < C; b++, pi++, pl++) {
+            const std::vector<uint32_t> &i1 = s.m_idx1[pi], &i2 = s.m_idx2[pi];
+            for (size_t k = 0; k < i1.size(); k++) {
+                const int fa = (int)i1[k], fb = (int)i2[k];
+                const int ma = inv[a][fa], mb = inv[b][fb];
+                if (gate && !epipolar_ok(gate->F + 9 * pl, gate->kps[a][fa], gate->kps[b][fb], gate->sigma2)) continue;
+                if (ma == -1 && mb == -1) {
+                    tr.resize((size_t)(ntr + 1) * C, -1);
+                    tr[(size_t)ntr * C + a] = fa;
+                    tr[(size_t)ntr * C + b] = fb;
+                    inv[a][fa] = ntr;
+                    inv[b][fb] = ntr;
+                    ntr++;
+                } else {
+                    if (ma == -1 && mb != -1) {
+                        if (tr[(size_t)mb * C + a] == -1) {
+                            tr[(size_t)mb * C + a] = fa;
+                            inv[a][fa] = mb;
+                        }
+                    }
+                    if (ma != -1 && mb != -1) {
+                        if (ma != mb) mergeable++;
+                    }
+                    if (ma != -1 && mb == -1) {
+                        tr[(size_t)ma * C + b] = fb;
+                        inv[b][fb] = ma;
+                    }
+                }
+            }
+        }
+    }
+    mergeable_out = mergeable;
+}
+
+// BruteForceMatch's output lists (MultiCameraFrame.cpp:1060-1078) + the track merge, host side,
+// after the k-NN tables landed.
 int Rig::finish_match(Slot &s, const Job &j)
 {
     (void)j;
     const int C = ncams;
     for (int f = 0; f < s.nframes_done; f++) {
-        std::vector<int32_t> &tr = s.tracks[f];
-        tr.clear();
-        int ntr = 0, mergeable = 0;
-        std::vector<std::vector<int>> inv(C);
-        for (int c = 0; c < C; c++) inv[c].assign(s.match_counts[f * C + c], -1);
         int pi = f * npp;
         for (int a = 0; a < C - 1; a++) {
             for (int b = a + 1; b < C; b++, pi++) {
@@ -747,35 +807,9 @@ int Rig::finish_match(Slot &s, const Job &j)
                     const KnnRow &r = rows[q];
                     if (knn_accept(r)) { i1.push_back((uint32_t)q); i2.push_back((uint32_t)knn_idx0(r)); }
                 }
-                for (size_t k = 0; k < i1.size(); k++) {
-                    const int fa = (int)i1[k], fb = (int)i2[k];
-                    const int ma = inv[a][fa], mb = inv[b][fb];
-                    if (ma == -1 && mb == -1) {
-                        tr.resize((size_t)(ntr + 1) * C, -1);
-                        tr[(size_t)ntr * C + a] = fa;
-                        tr[(size_t)ntr * C + b] = fb;
-                        inv[a][fa] = ntr;
-                        inv[b][fb] = ntr;
-                        ntr++;
-                    } else {
-                        if (ma == -1 && mb != -1) {
-                            if (tr[(size_t)mb * C + a] == -1) {
-                                tr[(size_t)mb * C + a] = fa;
-                                inv[a][fa] = mb;
-                            }
-                        }
-                        if (ma != -1 && mb != -1) {
-                            if (ma != mb) mergeable++;
-                        }
-                        if (ma != -1 && mb == -1) {
-                            tr[(size_t)ma * C + b] = fb;
-                            inv[b][fb] = ma;
-                        }
-                    }
-                }
             }
         }
-        s.mergeable[f] = mergeable;
+        merge_tracks(s, f, nullptr, s.tracks[f], s.mergeable[f]);
     }
     if (s.npairs_done > 0) {
         float m = 0;

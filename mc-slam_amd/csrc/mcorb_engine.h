@@ -129,6 +129,14 @@ struct Slot {
     std::string err;
 };
 
+// inputs of the old=true epipolar check: F per camera pair (i<j, row-major 3x3, x_j^T F x_i = 0), the
+// per-camera keypoints the reference reads (image_kps_undist) and the extractor's sigma2 table
+struct EpipolarGate {
+    const double *F;
+    const mcorb_keypoint *const *kps;
+    const float *sigma2;
+};
+
 class Rig {
 public:
     Rig() = default;
@@ -151,6 +159,8 @@ public:
     std::vector<Slot *> slots;
     WorkerPool *pool = nullptr;
     std::vector<SelectScratch *> scratch;   // one per worker
+
+    void merge_tracks(Slot &s, int f, const EpipolarGate *gate, std::vector<int32_t> &tr, int &mergeable_out) const;
 
 private:
     void driver(Slot *s);

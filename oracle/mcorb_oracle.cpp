@@ -18,6 +18,7 @@
 #include <limits.h>
 
 #include <algorithm>
+#include <cmath>
 #include <list>
 #include <utility>
 #include <vector>
@@ -1023,11 +1024,16 @@ extern "C" int orc_bruteforce_match(const uint8_t *q, int nq, const uint8_t *t, 
     return n;
 }
 
-/* MultiCameraFrame::computeIntraMatches(matches, old=false), :1100-1288 */
-extern "C" int orc_intra_matches(const uint8_t *const *desc, const int *n, int ncams,
-                                 float dist_thresh, float neigh_ratio,
-                                 int32_t *tracks, int cap_tracks, int *mergeable)
+/* MultiCameraFrame::computeIntraMatches(matches, old), :1100-1288.  old=true when F != NULL: F holds one
+ * row-major 3x3 per pair (the Mat built at :1126-1142 -- that cv::Mat algebra is outside this restatement),
+ * kps[c] are image_kps_undist[c], sigma2 = GetScaleSigmaSquares(). */
+extern "C" int orc_intra_matches_epi(const uint8_t *const *desc, const int *n, int ncams,
+                                     float dist_thresh, float neigh_ratio, const double *Fall,
+                                     const orc_keypoint *const *kps, const float *sigma2,
+                                     int32_t *tracks, int cap_tracks, int *mergeable)
 {
+    const bool old = Fall != NULL;
+    int pair = 0;
     std::vector<std::vector<int> > match_inv_idx;
     for (int i = 0; i < ncams; i++) match_inv_idx.push_back(std::vector<int>(n[i], -1));
     std::vector<std::vector<int> > matches;   /* IntraMatch::matchIndex, widened to ncams */
@@ -1037,11 +1043,35 @@ extern "C" int orc_intra_matches(const uint8_t *const *desc, const int *n, int n
             std::vector<uint32_t> indices1(n[i] + 1), indices2(n[i] + 1);
             int nm = orc_bruteforce_match(desc[i], n[i], desc[j], n[j], dist_thresh, neigh_ratio,
                                           indices1.data(), indices2.data(), n[i]);
+            const double *F = old ? Fall + 9 * pair : NULL;   /* F.at<double>(r,c) = F[3*r+c] */
+            pair++;
             for (int k = 0; k < nm; k++) {
                 int cami_feat = indices1[k];
                 int camj_feat = indices2[k];
                 int match_idx = match_inv_idx[i][cami_feat];
                 int match_idx_2 = match_inv_idx[j][camj_feat];
+                if (old) {   /* :1178-1207 */
+                    const orc_keypoint &kp1 = kps[i][cami_feat], &kp2 = kps[j][camj_feat];
+                    bool res;
+                    float a = kp2.x * F[0] + kp2.y * F[3] + F[6];
+                    float b = kp2.x * F[1] + kp2.y * F[4] + F[7];
+                    float c = kp2.x * F[2] + kp2.y * F[5] + F[8];
+                    float den = a * a + b * b;
+                    den = den ? 1. / std::sqrt(den) : 1.;
+                    a *= den; b *= den; c *= den;
+                    den = a * a + b * b;
+                    float num = a * kp1.x + b * kp1.y + c;
+                    float dsqr;
+                    float check_thresh;
+                    if (den == 0)
+                        res = false;
+                    else {
+                        dsqr = num * num / den;
+                        check_thresh = 3.84 * sigma2[kp1.octave];
+                        res = dsqr < check_thresh ? true : false;
+                    }
+                    if (!res) continue;
+                }
                 if (match_idx == -1 && match_idx_2 == -1) {
                     std::vector<int> temp(ncams, -1);
                     temp[i] = cami_feat;
@@ -1072,6 +1102,13 @@ extern "C" int orc_intra_matches(const uint8_t *const *desc, const int *n, int n
     for (size_t m = 0; m < matches.size() && (int)m < cap_tracks; m++)
         for (int c = 0; c < ncams; c++) tracks[m * ncams + c] = matches[m][c];
     return (int)matches.size();
+}
+
+extern "C" int orc_intra_matches(const uint8_t *const *desc, const int *n, int ncams,
+                                 float dist_thresh, float neigh_ratio,
+                                 int32_t *tracks, int cap_tracks, int *mergeable)
+{
+    return orc_intra_matches_epi(desc, n, ncams, dist_thresh, neigh_ratio, NULL, NULL, NULL, tracks, cap_tracks, mergeable);
 }
 
 /* MultiCameraFrame::computeRepresentativeDesc, :530-567 */

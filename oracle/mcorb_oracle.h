@@ -130,6 +130,12 @@ int orc_bruteforce_match(const uint8_t *q, int nq, const uint8_t *t, int nt,
 int orc_intra_matches(const uint8_t *const *desc, const int *n, int ncams,
                       float dist_thresh, float neigh_ratio,
                       int32_t *tracks, int cap_tracks, int *mergeable);
+/* the same with old=true: epipolar check of every pair (:1178-1207) against F (one row-major 3x3 per
+ * camera pair, the matrix of :1142), image_kps_undist and GetScaleSigmaSquares() */
+int orc_intra_matches_epi(const uint8_t *const *desc, const int *n, int ncams,
+                          float dist_thresh, float neigh_ratio, const double *F,
+                          const orc_keypoint *const *kps, const float *sigma2,
+                          int32_t *tracks, int cap_tracks, int *mergeable);
 /* MultiCameraFrame::computeRepresentativeDesc, :530-567 (least median distance) */
 int orc_representative_desc(const uint8_t *descs, int n);
 

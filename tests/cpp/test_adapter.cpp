@@ -67,6 +67,18 @@ int main(int argc, char **argv)
         for (auto &m : matches) ht = fnv(ht, m.matchIndex.data(), (size_t)C * sizeof(int));
         printf("rig features=%016llx matches=%zu/%016llx tracks=%zu/%016llx mergeable=%d\n", (unsigned long long)hr, nm,
                (unsigned long long)hm, matches.size(), (unsigned long long)ht, fr.cnt_mergable_matches);
+
+        // computeIntraMatches(matches, true): side-by-side rig with K = I, F = [t]x for every pair
+        std::vector<double> F;
+        for (int q = 0; q < C * (C - 1) / 2; q++) {
+            const double f[9] = {0, 0, 0, 0, 0, -1, 0, 1, 0};
+            F.insert(F.end(), f, f + 9);
+        }
+        fr.setFundamental(F);
+        fr.computeIntraMatches(matches, true);
+        uint64_t he = 1469598103934665603ULL;
+        for (auto &m : matches) he = fnv(he, m.matchIndex.data(), (size_t)C * sizeof(int));
+        printf("epipolar tracks=%zu/%016llx mergeable=%d\n", matches.size(), (unsigned long long)he, fr.cnt_mergable_matches);
     } catch (const std::exception &e) {
         fprintf(stderr, "FAILED: %s\n", e.what());
         return 1;

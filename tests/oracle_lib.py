@@ -272,7 +272,8 @@ def bruteforce_match(q, t, dist_thresh=75.0, ratio=0.85):
     return i1[:n].copy(), i2[:n].copy()
 
 
-def intra_matches(descs, dist_thresh=75.0, ratio=0.85):
+def intra_matches(descs, dist_thresh=75.0, ratio=0.85, F=None, kps=None, sigma2=None):
+    """F given -> computeIntraMatches(matches, old=true) with the epipolar check."""
     descs = [np.ascontiguousarray(d, np.uint8).reshape(-1, 32) for d in descs]
     nc = len(descs)
     ptrs = (C.c_void_p * nc)(*[_ptr(d) for d in descs])
@@ -280,6 +281,17 @@ def intra_matches(descs, dist_thresh=75.0, ratio=0.85):
     cap = int(ns.sum()) + 1
     tracks = np.full((cap, nc), -1, np.int32)
     merg = C.c_int()
+    if F is not None:
+        F = np.ascontiguousarray(F, np.float64)
+        kps = [np.ascontiguousarray(k, KP_DTYPE) for k in kps]
+        kp_ptrs = (C.c_void_p * nc)(*[_ptr(k) for k in kps])
+        sigma2 = np.ascontiguousarray(sigma2, np.float32)
+        f = lib().orc_intra_matches_epi
+        f.argtypes = [C.POINTER(C.c_void_p), _ip, C.c_int, C.c_float, C.c_float, C.c_void_p, C.POINTER(C.c_void_p),
+                      C.c_void_p, _i32p, C.c_int, _ip]
+        f.restype = C.c_int
+        n = f(ptrs, _ptr(ns, _ip), nc, dist_thresh, ratio, _ptr(F), kp_ptrs, _ptr(sigma2), _ptr(tracks, _i32p), cap, C.byref(merg))
+        return tracks[:n].copy(), merg.value
     n = lib().orc_intra_matches(ptrs, _ptr(ns, _ip), nc, dist_thresh, ratio, _ptr(tracks, _i32p), cap,
                                 C.byref(merg))
     return tracks[:n].copy(), merg.value

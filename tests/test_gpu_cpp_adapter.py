@@ -63,3 +63,9 @@ def test_cpp_adapter_matches_oracle():
         ht = fnv(ht, row.astype(np.int32).tobytes())
     want = "features=%016x matches=%d/%016x tracks=%d/%016x mergeable=%d" % (hr, nm, hm, len(tr), ht, mg)
     assert lines["rig"].strip() == want
+    Fm = np.tile(np.array([[0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]]), (C * (C - 1) // 2, 1, 1))
+    tr, mg = O.intra_matches([o[2] for o in ora], F=Fm, kps=[o[1] for o in ora], sigma2=O.OracleExtractor(N).tables()["sigma2"])
+    he = F0
+    for row in tr:
+        he = fnv(he, row.astype(np.int32).tobytes())
+    assert lines["epipolar"].strip() == "tracks=%d/%016x mergeable=%d" % (len(tr), he, mg)

@@ -178,6 +178,50 @@ def test_multicameraframe_mirror(mc):
     assert np.mean(np.abs(k1["y"] - k2["y"]) < 1) > 0.8
 
 
+def _rig_calibration(C, W, H, seed=None):
+    """Side-by-side rig (baseline along x).  seed: add small random rotations / offsets (general F)."""
+    K = np.array([[0.8 * W, 0, W / 2.0], [0, 0.8 * W, H / 2.0], [0, 0, 1]], np.float64)
+    rng = np.random.default_rng(seed) if seed is not None else None
+    Ks, Rs, ts = [], [], []
+    for c in range(C):
+        R, t = np.eye(3), np.array([-0.2 * c, 0.0, 0.0])
+        if rng is not None and c > 0:
+            w = rng.normal(0, 0.004, 3)
+            Wx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+            R = np.eye(3) + Wx + 0.5 * Wx @ Wx
+            t = t + rng.normal(0, 0.01, 3)
+        Ks.append(K); Rs.append(R); ts.append(t.reshape(3, 1))
+    return Ks, Rs, ts
+
+
+@pytest.mark.parametrize("seed", [None, 3, 4])
+def test_intra_matches_with_epipolar_gate(mc, seed):
+    """computeIntraMatches(matches, old=true) (MultiCameraFrame.cpp:1123-1143,1178-1207)."""
+    C, W, H = 4, 640, 480
+    imgs = [mc.synth_rig_frame(9, C, c, W, H) for c in range(C)]
+    fr = mc.MultiCameraFrame(C, W, H, nfeatures=1000)
+    fr.setData([im.astype(np.float32) / np.float32(255.0) for im in imgs])
+    fr.extractFeaturesParallel()
+    fr.setCalibration(*_rig_calibration(C, W, H, seed))
+    ora = [O.OracleExtractor(1000)(im) for im in imgs]
+    sigma2 = O.OracleExtractor(1000).tables()["sigma2"]
+    plain = fr.computeIntraMatches(False)
+    gated = fr.computeIntraMatches(True)
+    otr, omg = O.intra_matches([o[2] for o in ora], F=fr.F_mats, kps=[o[1] for o in ora], sigma2=sigma2)
+    got = np.array([m.matchIndex for m in gated], np.int32).reshape(-1, C)
+    assert np.array_equal(got, otr) and fr.cnt_mergable_matches == omg
+    npl = sum(int((np.array(m.matchIndex) >= 0).sum()) for m in plain)
+    ngt = int((got >= 0).sum())
+    assert 0 < ngt < npl, "the gate must reject some, not all, of the BruteForceMatch pairs (%d of %d)" % (ngt, npl)
+    # caller-supplied image_kps_undist: shift camera 1 by half a pixel -> different decisions, still equal to the oracle
+    und = [o[1].copy() for o in ora]
+    und[1]["y"] += np.float32(0.5)
+    gated2 = fr.computeIntraMatches(True, kps_undist=und)
+    otr2, _ = O.intra_matches([o[2] for o in ora], F=fr.F_mats, kps=und, sigma2=sigma2)
+    assert np.array_equal(np.array([m.matchIndex for m in gated2], np.int32).reshape(-1, C), otr2)
+    assert not np.array_equal(otr2, otr)
+
+
 # --------------------------------------------------------------------------------------------
 # batching, slots, determinism
 # --------------------------------------------------------------------------------------------

@@ -391,3 +391,25 @@ def test_extract_error_paths():
     flat = np.full((480, 640), 90, np.uint8)                               # no corner anywhere
     mono, k, d = ex(flat)
     assert mono == 0 and len(k) == 0
+
+
+def test_epipolar_gate_known_answer():
+    """computeIntraMatches(old=true), MultiCameraFrame.cpp:1178-1207.  With K = I and a pure x translation
+    F = [t]x, so the line of (x2, y2) in image i is y = y2 and the check reads (y1-y2)^2 < 3.84*sigma2[octave]:
+    |dy| < 1.9596 at octave 0, < 2.3515 at octave 1 (sigma2 = 1.44)."""
+    rng = np.random.default_rng(0)
+    d = rng.integers(0, 256, (4, 32), dtype=np.uint8)        # 4 distinct descriptors, identical in both cameras
+    F = np.array([[[0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]]])
+    sigma2 = np.array([1.0, 1.44], np.float32)
+    k1 = np.zeros(4, O.KP_DTYPE); k2 = np.zeros(4, O.KP_DTYPE)
+    k1["x"] = [10, 20, 30, 40]; k2["x"] = [15, 25, 35, 45]
+    k1["y"] = 100.0
+    k1["octave"] = [0, 0, 1, 1]
+    k2["y"] = [101.9, 102.0, 102.3, 102.4]
+    tr, _ = O.intra_matches([d, d], F=F, kps=[k1, k2], sigma2=sigma2)
+    assert tr.tolist() == [[0, 0], [2, 2]]
+    tr, _ = O.intra_matches([d, d])
+    assert tr.tolist() == [[0, 0], [1, 1], [2, 2], [3, 3]]
+    # a degenerate F (all zero) gives a = b = 0: den stays 0 after normalisation and the pair is rejected (:1191-1192)
+    tr, _ = O.intra_matches([d, d], F=np.zeros((1, 3, 3)), kps=[k1, k2], sigma2=sigma2)
+    assert len(tr) == 0
