@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--slots", type=int, default=None, help="buffer sets in flight per rank (default 6; 9 on the N>1 path)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-frames", type=int, default=24)
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (use when profiling kernels)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); 'gloo' only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses device 0")
     ap.add_argument("--force-dist", action="store_true",
@@ -305,6 +306,14 @@ def main():
         tr, _ = rig.tracks(0, slot=0)
         ok &= np.array_equal(tr, tracks)
         out["gpu_equals_oracle_frame0"] = bool(ok)
+    if N == 1 and not DIST and not args.no_latency:
+        # one rig frame at a time, nothing in flight (how MC-SLAM's tracking loop calls the front-end): host u8 images in,
+        # keypoints / descriptors / tracks back on the host.  Not part of `value`.
+        rig.close()
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from latency import measure
+        lat = measure(mcorb, NCAMS, W, H, NFEAT, frames=100)
+        out["single_frame_latency_ms"] = {k: lat[k] for k in ("upload_ms", "extract_match_ms", "readback_ms", "total_ms", "total_p95_ms")}
     print(json.dumps(out), flush=True)
     rig.close()
     if dist is not None:

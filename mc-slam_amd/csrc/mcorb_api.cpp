@@ -602,9 +602,10 @@ int mcorb_host_select(const uint32_t *packed, int n, int minX, int maxX, int min
     static thread_local SelectScratch sc;
     std::vector<uint32_t> sorted;
     std::vector<int> perm, bstart;
-    host_bucket_sort(packed, n, P, sorted, perm, bstart);   // what k_compact does on the device
+    std::vector<mcorb::BucketBest> bbest;
+    host_bucket_sort(packed, n, P, sorted, perm, bstart, bbest);   // what k_compact does on the device
     std::vector<int> out((size_t)std::max(nfeatures_level, 0) + 64 + 8);
-    const int r = select_octree(sorted.data(), bstart.data(), n, P, out.data(), sc);
+    const int r = select_octree(sorted.data(), bstart.data(), bbest.data(), n, P, out.data(), sc);
     if (r < 0) { set_error("host_select: level too tall"); return MCORB_E_SIZE; }
     if (r > cap) { set_error("host_select: output too small"); return MCORB_E_CAP; }
     for (int i = 0; i < r; i++) out_idx[i] = perm[out[i]];

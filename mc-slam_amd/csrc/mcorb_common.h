@@ -20,6 +20,12 @@ __host__ __device__ inline int cand_x(uint32_t p) { return (int)((p >> 8) & 0xff
 __host__ __device__ inline int cand_y(uint32_t p) { return (int)(p >> 20); }
 __host__ __device__ inline int cand_resp(uint32_t p) { return (int)(p & 0xffu); }
 
+// Winner of the reference's final pick inside one path-code bucket (ORBextractor.cpp:757-775):
+// key = response << 23 | (kPickOrderMask - position in vToDistributeKeys order), larger key wins;
+// pos = index of that candidate in the level's bucket-sorted list.  key == 0: empty bucket.
+constexpr int kPickOrderMask = (1 << 23) - 1;
+struct BucketBest { uint32_t key, pos; };
+
 // Packed selected keypoint handed back to the device: level (4) | y (14) | x (14), level coordinates.
 __host__ __device__ inline uint32_t pack_sel(int level, int x, int y) { return ((uint32_t)level << 28) | ((uint32_t)y << 14) | (uint32_t)x; }
 

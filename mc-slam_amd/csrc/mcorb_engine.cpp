@@ -11,11 +11,15 @@
 // batches can be in flight and the host stage of one overlaps the GPU phases of others.
 #include "mcorb_engine.h"
 
+#include <alloca.h>
 #include <math.h>
+#include <stdio.h>
+#include <time.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <new>
 #include <cmath>
 #include <chrono>
 
@@ -179,8 +183,32 @@ int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g
     if (g.kcap > 65535) { set_error("nfeatures too large (k-NN index is 16 bits)"); return MCORB_E_ARG; }
     // default: one candidate slot per 4 level-0 pixels (measured: ~1 per 28 px on the synthetic rig frames)
     g.candCap = p.cand_cap > 0 ? p.cand_cap : (int)align_up(std::max((size_t)65536, (size_t)W * H / 4), 4096);
+    if (g.candCap > kPickOrderMask) { set_error("cand_cap too large (pick order is 23 bits)"); return MCORB_E_ARG; }
     return MCORB_OK;
 }
+
+// ---------------------------------------------------------------------------
+// optional host-side profile (MCORB_HOST_PROF=1): wall and thread-CPU time of the selection tasks
+// ---------------------------------------------------------------------------
+namespace HostProf {
+static const bool on = getenv("MCORB_HOST_PROF") != nullptr;
+static std::atomic<long long> wall[4], cpu[4], cnt[4];
+static inline long long now(clockid_t c) { timespec t; clock_gettime(c, &t); return t.tv_sec * 1000000000LL + t.tv_nsec; }
+struct Scope {
+    int k; long long w0 = 0, c0 = 0;
+    explicit Scope(int k_) : k(k_) { if (on) { w0 = now(CLOCK_MONOTONIC); c0 = now(CLOCK_THREAD_CPUTIME_ID); } }
+    ~Scope() { if (on) { wall[k] += now(CLOCK_MONOTONIC) - w0; cpu[k] += now(CLOCK_THREAD_CPUTIME_ID) - c0; cnt[k]++; } }
+};
+static void report()
+{
+    if (!on) return;
+    const char *names[4] = {"select task (per image)", "  select_octree x levels", "finish_match (per job)", "prepare_match (per job)"};
+    for (int k = 0; k < 4; k++)
+        if (cnt[k].load())
+            fprintf(stderr, "[mcorb host prof] %-26s n=%lld wall %.1f us cpu %.1f us\n", names[k], cnt[k].load(),
+                    wall[k].load() / 1e3 / cnt[k].load(), cpu[k].load() / 1e3 / cnt[k].load());
+}
+}  // namespace HostProf
 
 // ---------------------------------------------------------------------------
 // worker pool
@@ -338,6 +366,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     HIPCHK(upload_umax(tab.umax));
 
     int nthreads = p.host_threads > 0 ? p.host_threads : (int)std::thread::hardware_concurrency();
+    if (getenv("MCORB_HOST_THREADS")) nthreads = atoi(getenv("MCORB_HOST_THREADS"));
     if (nthreads < 1) nthreads = 1;
     // default: one worker per image of a batch, at most 16 (the CPU share that goes with one GPU)
     if (p.host_threads <= 0) nthreads = std::min(nthreads, std::max(2, std::min(max_images, 16)));
@@ -356,7 +385,14 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         else HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&s->st_copy, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&s->st_dma, hipStreamNonBlocking));
-        for (auto &e : s->ev) HIPCHK(hipEventCreate(&e));
+        // events a driver thread sleeps on (3 compaction, 10 compute stream, 11 DMA stream): with more than two slots
+        // the drivers would otherwise spin on as many cores as there are slots and starve the selection workers
+        const char *sync_env = getenv("MCORB_SYNC");
+        const bool blocking = sync_env ? !strcmp(sync_env, "block") : nslots > 2;
+        for (int e = 0; e < 12; e++) {
+            const bool waited = e == 3 || e == 10 || e == 11;
+            HIPCHK(hipEventCreateWithFlags(&s->ev[e], waited && blocking ? hipEventBlockingSync : hipEventDefault));
+        }
         const size_t M = (size_t)max_images;
         TRY(dev_alloc(&s->d_pyr, M * geom.imgBytes));
         TRY(dev_alloc(&s->d_blur, M * geom.imgBytes));
@@ -366,6 +402,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         TRY(dev_alloc(&s->d_cellcnt, M * geom.cells));
         TRY(dev_alloc(&s->d_sorted, M * geom.candCap));
         TRY(host_alloc(&s->h_bstart, M * geom.bucketTotal));
+        TRY(host_alloc(&s->h_bbest, M * geom.bucketTotal));
         TRY(dev_alloc(&s->d_desc, M * geom.kcap * 32));
         HIPCHK(hipMemset(s->d_desc, 0, M * geom.kcap * 32));
         TRY(dev_alloc(&s->d_angles, M * geom.kcap));
@@ -405,6 +442,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
 
 Rig::~Rig()
 {
+    HostProf::report();
     for (Slot *s : slots) {
         if (s->th.joinable()) {
             {
@@ -419,7 +457,7 @@ Rig::~Rig()
         if (s->st_copy) (void)hipStreamSynchronize(s->st_copy);
         if (s->st_dma) (void)hipStreamSynchronize(s->st_dma);
         (void)hipFree(s->d_pyr); (void)hipFree(s->d_blur); (void)hipFree(s->d_desc); (void)hipFree(s->d_cellkp);
-        (void)hipFree(s->d_cellcnt); (void)hipFree(s->d_sorted); (void)hipHostFree(s->h_bstart); (void)hipFree(s->d_angles); (void)hipFree(s->d_part); (void)hipFree(s->d_f32);
+        (void)hipFree(s->d_cellcnt); (void)hipFree(s->d_sorted); (void)hipHostFree(s->h_bstart); (void)hipHostFree(s->h_bbest); (void)hipFree(s->d_angles); (void)hipFree(s->d_part); (void)hipFree(s->d_f32);
         (void)hipHostFree(s->h_cand); (void)hipHostFree(s->h_lvloff); (void)hipHostFree(s->h_overflow);
         (void)hipHostFree(s->h_knn); (void)hipHostFree(s->h_ctrl); (void)hipFree(s->d_ctrl);
         (void)hipHostFree(s->h_stage);
@@ -566,7 +604,7 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
     // compaction writes the candidates over PCIe into host-mapped memory: run it on the side stream so
     // the blur (which does not depend on it) overlaps the transfer
     HIPCHK(hipStreamWaitEvent(s.st_copy, s.ev[2], 0));
-    launch_compact(s.st_copy, s.d_cellkp, s.d_cellcnt, geom, s.d_sorted, s.h_cand, s.h_lvloff, s.h_bstart, s.h_overflow,
+    launch_compact(s.st_copy, s.d_cellkp, s.d_cellcnt, geom, s.d_sorted, s.h_cand, s.h_lvloff, s.h_bstart, s.h_bbest, s.h_overflow,
                    j.nimg);
     HIPCHK(hipEventRecord(s.ev[3], s.st_copy));
     launch_blur(s.st, s.d_pyr, s.d_blur, geom, j.nimg);
@@ -589,8 +627,10 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     // selection + assembly: one task per image (all its levels); the host side of a level is now
     // ~10 us of tree logic on GPU-bucketed candidates, so finer tasks would only pay pool overhead
     pool->parallel_for(nimg, [&](int m, int w) {
+        HostProf::Scope prof_task(0);
         const int *lo = s.h_lvloff + (size_t)m * (kMaxLevels + 1);
         int total = 0;
+        HostProf::Scope *prof_sel = new (alloca(sizeof(HostProf::Scope))) HostProf::Scope(1);
         for (int level = 0; level < L; level++) {
             const int n = lo[level + 1] - lo[level];
             std::vector<int> &out = s.sel_idx[(size_t)m * L + level];
@@ -598,12 +638,14 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
             int r = 0;
             if (n > 0)
                 r = select_octree(s.h_cand + (size_t)m * geom.candCap + lo[level],
-                                  s.h_bstart + (size_t)m * geom.bucketTotal + geom.lv[level].bucket0, n, selp[level],
+                                  s.h_bstart + (size_t)m * geom.bucketTotal + geom.lv[level].bucket0,
+                                  s.h_bbest + (size_t)m * geom.bucketTotal + geom.lv[level].bucket0, n, selp[level],
                                   out.data(), *scratch[w]);
             if (r < 0) { bad.store(1); r = 0; }
             out.resize(r);
             total += r;
         }
+        prof_sel->~Scope();
         // assembly (ORBextractor.cpp:1103-1170): final order, lapping partition, coordinate scaling
         if (total > geom.kcap) { bad.store(2); total = 0; }
         std::vector<mcorb_keypoint> &K = s.kps[m];
@@ -656,8 +698,9 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     if (then_match) TRY(enqueue_match(s, j, true));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s.ev[10], s.st));
-    HIPCHK(hipEventSynchronize(s.ev[10]));   // event, not stream: the compute stream may be shared between slots
-    HIPCHK(hipStreamSynchronize(s.st_dma));
+    HIPCHK(hipEventRecord(s.ev[11], s.st_dma));
+    HIPCHK(hipEventSynchronize(s.ev[10]));   // events, not streams: the compute stream may be shared between slots
+    HIPCHK(hipEventSynchronize(s.ev[11]));
     if (params.orientation)
         for (int m = 0; m < nimg; m++)
             for (size_t k = 0; k < s.kps[m].size(); k++) s.kps[m][k].angle = s.h_angles[(size_t)m * geom.kcap + k];
@@ -679,6 +722,7 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
 // fills the host side of the control block for a match: per-(frame,cam) sets/counts and the pair list
 int Rig::prepare_match(Slot &s, const Job &j)
 {
+    HostProf::Scope prof(3);
     const bool ext = j.ext_desc != nullptr;
     if (j.nframes < 1 || j.nframes > max_frames || (!ext && j.nframes * ncams > s.nimg_done)) {
         set_error("match: bad frame count or features not extracted");
@@ -794,6 +838,7 @@ void Rig::merge_tracks(Slot &s, int f, const EpipolarGate *gate, std::vector<int
 int Rig::finish_match(Slot &s, const Job &j)
 {
     (void)j;
+    HostProf::Scope prof(2);
     const int C = ncams;
     for (int f = 0; f < s.nframes_done; f++) {
         int pi = f * npp;

@@ -94,6 +94,7 @@ struct Slot {
     // host, device-mapped (kernels write/read these directly over PCIe)
     uint32_t *h_cand = nullptr;
     int *h_lvloff = nullptr, *h_overflow = nullptr, *h_bstart = nullptr;
+    BucketBest *h_bbest = nullptr;   // per bucket: winner of the final pick (k_compact)
     KnnRow *h_knn = nullptr;
     // control block: one pinned host buffer + one device mirror, copied with a single
     // hipMemcpyAsync: [extcounts 4096 ints][nsel][pairs][sel]

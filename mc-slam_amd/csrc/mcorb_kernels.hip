@@ -273,8 +273,16 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     __syncthreads();   // single-wave workgroup: lowers to a wait, not an s_barrier
 
     const float rcp_tp = 1.0f / (float)TP;
-    const int tlo = iniTh < minTh ? iniTh : minTh;
+    uint32_t *dst = cell_kp + ((size_t)img * g.cells + cell) * g.cellCap;
+    int total = 0;
 
+    // The reference calls cv::FAST at iniTh and, only when the cell came out empty, again at minTh
+    // (ORBextractor.cpp:847-856).  Same here: everything below runs at T = iniTh first (NMS only ever
+    // looks at scores above T, so pixels failing the tests at T need no score), and the wave-uniform
+    // retry at minTh is paid by empty cells only.
+    int T = iniTh;
+#pragma unroll 1
+    for (int attempt = 0; attempt < 2; attempt++) {
     // ---- pass 1: 4-point test, 4 horizontally adjacent pixels per lane: five aligned LDS dwords
     //      (centre, left, right, 3 rows up, 3 rows down) feed packed 16-bit min/max; survivors are
     //      appended in raster order (lane-major, then byte position) ----
@@ -314,10 +322,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             // only the first / last group of a row can hold columns outside [cmin, cmax)
             const int col = 4 * gq;
             const bool in = wr < nw;
-            const bool c0 = in && mm[0].x > tlo && col >= cmin && col < cmax;
-            const bool c1 = in && mm[0].y > tlo && col + 1 >= cmin && col + 1 < cmax;
-            const bool c2 = in && mm[1].x > tlo && col + 2 >= cmin && col + 2 < cmax;
-            const bool c3 = in && mm[1].y > tlo && col + 3 >= cmin && col + 3 < cmax;
+            const bool c0 = in && mm[0].x > T && col >= cmin && col < cmax;
+            const bool c1 = in && mm[0].y > T && col + 1 >= cmin && col + 1 < cmax;
+            const bool c2 = in && mm[1].x > T && col + 2 >= cmin && col + 2 < cmax;
+            const bool c3 = in && mm[1].y > T && col + 3 >= cmin && col + 3 < cmax;
             const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1), b2 = __ballot(c2), b3 = __ballot(c3);
             int o = lane_rank(b3, lane_rank(b2, lane_rank(b1, lane_rank(b0, nA))));
             if (c0) work[o++] = (uint16_t)pos;
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         bool cand = false;
         if (i < nA) {
             pos = work[i];
-            cand = fast_even8_max(tile + pos, TP) > tlo;
+            cand = fast_even8_max(tile + pos, TP) > T;
         }
         const unsigned long long b = __ballot(cand);
         __syncthreads();
@@ -353,12 +361,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     }
     __syncthreads();
 
-    // ---- pass 3: NMS over the work list at iniTh, then (only if the cell came out empty) at minTh;
-    //      the list is in raster order, so keypoints are emitted in cv::FAST's order ----
-    uint32_t *dst = cell_kp + ((size_t)img * g.cells + cell) * g.cellCap;
-    int total = 0;
-    int T = iniTh;
-    for (int attempt = 0; attempt < 2; attempt++) {
+    // ---- pass 3: NMS over the work list; it is in raster order, so keypoints are emitted in cv::FAST's order ----
         for (int i0 = 0; i0 < nB; i0 += 64) {
             const int i = i0 + lane;
             bool keep = false;
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         }
         if (total || T == minTh) break;
         T = minTh;
+        __syncthreads();
     }
     if (lane == 0) *out_cnt = total;
 }
@@ -429,16 +433,22 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int *wsum, int *
 // (path_code(), depth g.lv[level].depth) with an LDS counting sort and hands the host the bucket
 // start offsets: the host-side DistributeOctTree logic then gets every node's key count in O(1)
 // and never has to partition the candidate list itself for the first `depth` splits.
-// Order inside a bucket is arbitrary; the selection only depends on the key SETS (the
-// "first maximum wins" tie is resolved from the coordinates, which encode the original order).
+// Order inside a bucket is arbitrary; the selection only depends on the key SETS.  The kernel also
+// finds each bucket's winner of the reference's final pick (largest response, first one in
+// vToDistributeKeys order on ties, ORBextractor.cpp:757-775): key = response << 23 | (2^23-1 - i)
+// with i the candidate's position in the unsorted level list (which IS vToDistributeKeys order),
+// LDS atomicMax per bucket, and ships (key, position in the sorted list) per bucket, so the host
+// never scans a node's keys unless the tree went deeper than the bucketing.
 __global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ cell_kp, const int *__restrict__ cell_cnt,
                                                   Geom g, uint32_t *__restrict__ sorted_dev, uint32_t *__restrict__ cand,
-                                                  int *__restrict__ lvl_off, int *__restrict__ bstart,
-                                                  int *__restrict__ overflow, int exclCap)
+                                                  int *__restrict__ lvl_off, int *__restrict__ bstart, BucketBest *__restrict__ bbest,
+                                                  int *__restrict__ overflow, int exclCap, int bktCap)
 {
-    extern __shared__ int sh[];     // excl[exclCap] | hist[nBuckets + 1]
+    extern __shared__ int sh[];     // excl[exclCap] | hist[bktCap] | bkey[bktCap] | bpos[bktCap]
     int *excl = sh;                 // exclusive offsets of this level's cells (+1 entry for the total)
     int *hist = sh + exclCap;
+    uint32_t *bkey = reinterpret_cast<uint32_t *>(hist + bktCap);
+    int *bpos = hist + 2 * bktCap;
     __shared__ int wsum[16];
     __shared__ int s_tot, s_base;
     const int tid = threadIdx.x;
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ c
     for (int c = tid; c < L.cell0; c += 1024) { const int v = cnt[c]; s += v < cap ? v : cap; }
     (void)block_exclusive_scan_1024(s, wsum, &s_base);
     const int base = s_base;
-    for (int b = tid; b <= B; b += 1024) hist[b] = 0;
+    for (int b = tid; b <= B; b += 1024) { hist[b] = 0; bkey[b] = 0; bpos[b] = 0; }
     __syncthreads();
 
     // exclusive scan over this level's cells: each thread owns a contiguous run of cells
@@ -491,7 +501,9 @@ __global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ c
             if (excl[mid] <= i) lo = mid; else hi = mid;
         }
         const uint32_t p = src[(size_t)lo * cap + (i - excl[lo])];
-        atomicAdd(&hist[path_code(cand_x(p), cand_y(p), W0, H0, L.nIni, L.hX, L.depth)], 1);
+        const uint32_t code = path_code(cand_x(p), cand_y(p), W0, H0, L.nIni, L.hX, L.depth);
+        atomicAdd(&hist[code], 1);
+        atomicMax(&bkey[code], ((uint32_t)cand_resp(p) << 23) | (uint32_t)(kPickOrderMask - i));
     }
     __syncthreads();
     // bucket starts: exclusive scan of the histogram (each thread owns a contiguous run of buckets)
@@ -519,10 +531,14 @@ __global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ c
             if (excl[mid] <= i) lo = mid; else hi = mid;
         }
         const uint32_t p = src[(size_t)lo * cap + (i - excl[lo])];
-        const int slot = atomicAdd(&hist[path_code(cand_x(p), cand_y(p), W0, H0, L.nIni, L.hX, L.depth)], 1);
+        const uint32_t code = path_code(cand_x(p), cand_y(p), W0, H0, L.nIni, L.hX, L.depth);
+        const int slot = atomicAdd(&hist[code], 1);
         sd[slot] = p;
+        if (bkey[code] == (((uint32_t)cand_resp(p) << 23) | (uint32_t)(kPickOrderMask - i))) bpos[code] = slot;   // keys are unique
     }
     __syncthreads();   // the workgroup's own global stores are visible to it after the barrier
+    BucketBest *bb_out = bbest + (size_t)img * g.bucketTotal + L.bucket0;
+    for (int b = tid; b < B; b += 1024) bb_out[b] = BucketBest{bkey[b], (uint32_t)bpos[b]};
     // coalesced copy-out over PCIe into host-mapped memory
     uint32_t *dst = cand + (size_t)img * g.candCap + base;
     for (int i = tid; i < T; i += 1024) dst[i] = sd[i];
@@ -1051,7 +1067,7 @@ void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, i
 }
 
 void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt, const Geom &g, uint32_t *sorted_dev,
-                    uint32_t *cand, int *lvl_off, int *bstart, int *overflow, int nimg)
+                    uint32_t *cand, int *lvl_off, int *bstart, BucketBest *bbest, int *overflow, int nimg)
 {
     int maxc = 1, maxb = 1;
     for (int l = 0; l < g.nlevels; l++) {
@@ -1059,8 +1075,9 @@ void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt
         maxb = maxb > g.lv[l].nBuckets ? maxb : g.lv[l].nBuckets;
     }
     const int exclCap = (maxc + 1 + 3) & ~3;
-    hipLaunchKernelGGL(k_compact, dim3(g.nlevels, nimg), dim3(1024), (size_t)(exclCap + maxb + 1) * sizeof(int), st, cell_kp,
-                       cell_cnt, g, sorted_dev, cand, lvl_off, bstart, overflow, exclCap);
+    const int bktCap = (maxb + 1 + 3) & ~3;
+    hipLaunchKernelGGL(k_compact, dim3(g.nlevels, nimg), dim3(1024), (size_t)(exclCap + 3 * bktCap) * sizeof(int), st, cell_kp,
+                       cell_cnt, g, sorted_dev, cand, lvl_off, bstart, bbest, overflow, exclCap, bktCap);
 }
 
 void launch_blur(hipStream_t st, const uint8_t *pyr, uint8_t *blur, const Geom &g, int nimg)

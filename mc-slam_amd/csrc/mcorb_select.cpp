@@ -117,7 +117,7 @@ static void divide(SelectScratch::Impl &S, const uint32_t *cand, const int *bsta
     }
 }
 
-int select_octree(const uint32_t *cand, const int *bstart, int n, const SelectParams &P, int *out_idx,
+int select_octree(const uint32_t *cand, const int *bstart, const BucketBest *bbest, int n, const SelectParams &P, int *out_idx,
                   SelectScratch &scratch)
 {
     SelectScratch::Impl &S = *scratch.impl;
@@ -208,6 +208,18 @@ int select_octree(const uint32_t *cand, const int *bstart, int n, const SelectPa
     int m = 0;
     for (int it = S.head; it >= 0; it = S.nodes[it].next) {
         const Node &nd = S.nodes[it];
+        if (nd.cnt == 1) { out_idx[m++] = nd.arena ? S.arena[nd.beg] : nd.beg; continue; }
+        if (!nd.arena) {
+            // the node is a run of buckets whose winners the GPU already found: the largest key wins
+            const int shift = 2 * (D - nd.d);
+            const BucketBest *bb = bbest + ((size_t)nd.code << shift);
+            const int nb = 1 << shift;
+            uint32_t bestKey = 0, bestPos = 0;
+            for (int b = 0; b < nb; b++)
+                if (bb[b].key > bestKey) { bestKey = bb[b].key; bestPos = bb[b].pos; }
+            out_idx[m++] = (int)bestPos;
+            continue;
+        }
         int best = -1, bestR = -1;
         uint64_t bestO = 0;
         for (int k = 0; k < nd.cnt; k++) {
@@ -228,7 +240,7 @@ int select_octree(const uint32_t *cand, const int *bstart, int n, const SelectPa
 // CPU statement of what k_compact does on the GPU for one level (used by the host-only test hook):
 // counting sort of the candidates by path code, bucket starts out.
 void host_bucket_sort(const uint32_t *cand, int n, const SelectParams &P, std::vector<uint32_t> &sorted,
-                      std::vector<int> &perm, std::vector<int> &bstart)
+                      std::vector<int> &perm, std::vector<int> &bstart, std::vector<BucketBest> &bbest)
 {
     const int B = P.nIni << (2 * P.depth);
     bstart.assign((size_t)B + 1, 0);
@@ -242,10 +254,13 @@ void host_bucket_sort(const uint32_t *cand, int n, const SelectParams &P, std::v
     std::vector<int> pos(bstart.begin(), bstart.end() - 1);
     sorted.resize(n);
     perm.resize(n);
+    bbest.assign((size_t)B, BucketBest{0, 0});
     for (int i = 0; i < n; i++) {
         const int s = pos[code[i]]++;
         sorted[s] = cand[i];
         perm[s] = i;
+        const uint32_t key = ((uint32_t)cand_resp(cand[i]) << 23) | (uint32_t)(kPickOrderMask - i);
+        if (key > bbest[code[i]].key) bbest[code[i]] = BucketBest{key, (uint32_t)s};
     }
 }
 

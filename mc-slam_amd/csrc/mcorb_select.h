@@ -31,11 +31,11 @@ SelectParams make_select_params(int minX, int maxX, int minY, int maxY, int N, i
 // nIni*4^depth + 1 bucket start offsets.  out_idx: indices INTO cand of the retained candidates
 // in the reference's result order; needs room for N + 64 entries.  Returns the count, or -2 if
 // the level is too tall for a root node (the reference divides by zero there).
-int select_octree(const uint32_t *cand, const int *bstart, int n, const SelectParams &P, int *out_idx,
+int select_octree(const uint32_t *cand, const int *bstart, const BucketBest *bbest, int n, const SelectParams &P, int *out_idx,
                   SelectScratch &scratch);
 
 // host statement of k_compact's counting sort for one level (test hook only)
 void host_bucket_sort(const uint32_t *cand, int n, const SelectParams &P, std::vector<uint32_t> &sorted,
-                      std::vector<int> &perm, std::vector<int> &bstart);
+                      std::vector<int> &perm, std::vector<int> &bstart, std::vector<BucketBest> &bbest);
 
 }  // namespace mcorb
