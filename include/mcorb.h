@@ -108,6 +108,8 @@ int mcorb_rig_extract(mcorb_rig *r, int slot, int nimg, int lap_x0, int lap_x1);
 int mcorb_rig_process_submit(mcorb_rig *r, int slot, int nframes, int lap_x0, int lap_x1,
                              float dist_thresh, float ratio);
 int mcorb_rig_process_wait(mcorb_rig *r, int slot);
+/* the same, synchronously on the calling thread (lowest latency for one frame at a time) */
+int mcorb_rig_process(mcorb_rig *r, int slot, int nframes, int lap_x0, int lap_x1, float dist_thresh, float ratio);
 
 /* results of image m of a slot: ORBextractor::operator() outputs
  * (ORBextractor.cpp:1085-1171): keypoints, N x 32 descriptors, monoIndex */

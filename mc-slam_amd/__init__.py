@@ -113,6 +113,10 @@ class Rig:
     def process_submit(self, nframes, slot=0, lap=(0, 0), dist_thresh=75.0, ratio=0.85):
         _lib.check(self.L.mcorb_rig_process_submit(self.h_rig, slot, nframes, lap[0], lap[1], dist_thresh, ratio))
 
+    def process(self, nframes, slot=0, lap=(0, 0), dist_thresh=75.0, ratio=0.85):
+        """extract + intra-rig match, synchronously on the calling thread."""
+        _lib.check(self.L.mcorb_rig_process(self.h_rig, slot, nframes, lap[0], lap[1], dist_thresh, ratio))
+
     def process_wait(self, slot=0):
         _lib.check(self.L.mcorb_rig_process_wait(self.h_rig, slot))
 

@@ -50,6 +50,7 @@ SIGNATURES = {
     "mcorb_rig_extract_wait": (_i, [_vp, _i]),
     "mcorb_rig_extract": (_i, [_vp, _i, _i, _i, _i]),
     "mcorb_rig_process_submit": (_i, [_vp, _i, _i, _i, _i, _f, _f]),
+    "mcorb_rig_process": (_i, [_vp, _i, _i, _i, _i, _f, _f]),
     "mcorb_rig_process_wait": (_i, [_vp, _i]),
     "mcorb_rig_num_keypoints": (_i, [_vp, _i, _i]),
     "mcorb_rig_get_features": (_i, [_vp, _i, _i, _vp, _vp, _i, _ip, _ip]),

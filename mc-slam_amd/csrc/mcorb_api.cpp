@@ -104,8 +104,10 @@ int mcorb_rig_extract_submit(mcorb_rig *r, int slot, int nimg, int lap_x0, int l
 int mcorb_rig_extract_wait(mcorb_rig *r, int slot) { return r ? r->rig.wait(slot) : MCORB_E_ARG; }
 int mcorb_rig_extract(mcorb_rig *r, int slot, int nimg, int lap_x0, int lap_x1)
 {
-    const int st = mcorb_rig_extract_submit(r, slot, nimg, lap_x0, lap_x1);
-    return st != MCORB_OK ? st : mcorb_rig_extract_wait(r, slot);
+    if (!r) return MCORB_E_ARG;
+    Job j;
+    j.kind = Job::EXTRACT; j.nimg = nimg; j.lap0 = lap_x0; j.lap1 = lap_x1;
+    return r->rig.run_sync(slot, j);
 }
 
 int mcorb_rig_process_submit(mcorb_rig *r, int slot, int nframes, int lap_x0, int lap_x1, float dist_thresh, float ratio)
@@ -128,8 +130,19 @@ int mcorb_rig_match_submit(mcorb_rig *r, int slot, int nframes, float dist_thres
 int mcorb_rig_match_wait(mcorb_rig *r, int slot) { return r ? r->rig.wait(slot) : MCORB_E_ARG; }
 int mcorb_rig_match(mcorb_rig *r, int slot, int nframes, float dist_thresh, float ratio)
 {
-    const int st = mcorb_rig_match_submit(r, slot, nframes, dist_thresh, ratio);
-    return st != MCORB_OK ? st : mcorb_rig_match_wait(r, slot);
+    if (!r) return MCORB_E_ARG;
+    Job j;
+    j.kind = Job::MATCH; j.nframes = nframes; j.dist_thresh = dist_thresh; j.ratio = ratio;
+    return r->rig.run_sync(slot, j);
+}
+/* extract + match of nframes rig frames in one synchronous call (process_submit + process_wait on the caller's thread) */
+int mcorb_rig_process(mcorb_rig *r, int slot, int nframes, int lap_x0, int lap_x1, float dist_thresh, float ratio)
+{
+    if (!r) return MCORB_E_ARG;
+    Job j;
+    j.kind = Job::PROCESS; j.nframes = nframes; j.nimg = nframes * r->rig.ncams; j.lap0 = lap_x0; j.lap1 = lap_x1;
+    j.dist_thresh = dist_thresh; j.ratio = ratio;
+    return r->rig.run_sync(slot, j);
 }
 
 static Slot *get_slot(mcorb_rig *r, int slot)

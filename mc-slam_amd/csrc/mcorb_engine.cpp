@@ -265,7 +265,7 @@ void WorkerPool::run(int widx)
         b->refs.fetch_sub(1, std::memory_order_acq_rel);
     }
 }
-void WorkerPool::parallel_for(int n, const std::function<void(int, int)> &fn)
+void WorkerPool::parallel_for(int n, const std::function<void(int, int)> &fn, int caller_widx)
 {
     if (n <= 0) return;
     Batch b;
@@ -277,6 +277,16 @@ void WorkerPool::parallel_for(int n, const std::function<void(int, int)> &fn)
         pending_.fetch_add(1, std::memory_order_acq_rel);
     }
     cv_.notify_all();
+    // the submitting thread works on its own batch too (with its own scratch index): a one-frame batch does not
+    // have to wait for a sleeping worker to wake up
+    if (caller_widx >= 0) {
+        for (;;) {
+            const int t = b.next.fetch_add(1);
+            if (t >= b.n) break;
+            fn(t, caller_widx);
+            b.done.fetch_add(1);
+        }
+    }
     {
         std::unique_lock<std::mutex> lk(b.m);
         b.cv.wait(lk, [&b] { return b.done.load() >= b.n; });
@@ -372,7 +382,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     if (p.host_threads <= 0) nthreads = std::min(nthreads, std::max(2, std::min(max_images, 16)));
     nthreads = std::min(nthreads, 64);
     pool = new WorkerPool(nthreads);
-    for (int i = 0; i < nthreads; i++) scratch.push_back(new SelectScratch);
+    pool_threads = nthreads;
+    for (int i = 0; i < nthreads + nslots; i++) scratch.push_back(new SelectScratch);   // workers, then one per slot's submitting thread
 
     const int npairs_max = std::max(1, npp * max_frames);
     const int nchunks = (geom.kcap + kKnnChunk - 1) / kKnnChunk;
@@ -548,6 +559,59 @@ int Rig::wait(int slot)
     return s.status;
 }
 
+int Rig::execute(Slot &s, const Job &j)
+{
+    int st = MCORB_OK;
+    switch (j.kind) {
+    case Job::EXTRACT:
+        st = run_extract_phaseA(s, j);
+        if (st == MCORB_OK) st = run_select_and_describe(s, j, false);
+        break;
+    case Job::PROCESS:
+        st = run_extract_phaseA(s, j);
+        if (st == MCORB_OK) st = run_select_and_describe(s, j, true);
+        if (st == MCORB_OK) st = finish_match(s, j);
+        break;
+    case Job::MATCH:
+        st = enqueue_match(s, j, false);
+        if (st == MCORB_OK) {
+            hipError_t e = hipEventRecord(s.ev[10], s.st);
+            if (e == hipSuccess) e = hipEventSynchronize(s.ev[10]);
+            if (e != hipSuccess) { set_error(hipGetErrorString(e)); st = MCORB_E_HIP; }
+        }
+        if (st == MCORB_OK) st = finish_match(s, j);
+        break;
+    default: break;
+    }
+    return st;
+}
+
+// Synchronous entry points run the job on the calling thread: no hand-off to the slot's driver thread and back
+// (two futex wake-ups, ~50-100 us of a 0.6 ms single-frame call).
+int Rig::run_sync(int slot, const Job &job)
+{
+    if (slot < 0 || slot >= (int)slots.size()) { set_error("bad slot"); return MCORB_E_ARG; }
+    Slot &s = *slots[slot];
+    {
+        std::lock_guard<std::mutex> lk(s.m);
+        if (s.busy) { set_error("slot busy"); return MCORB_E_STATE; }
+        s.busy = true;
+        s.inline_job = true;   // the driver thread must not pick this one up
+        s.status = MCORB_OK;
+    }
+    (void)hipSetDevice(device);
+    const int st = execute(s, job);
+    {
+        std::lock_guard<std::mutex> lk(s.m);
+        s.status = st;
+        if (st != MCORB_OK) s.err = get_error();
+        s.busy = false;
+        s.inline_job = false;
+    }
+    s.cv.notify_all();
+    return st;
+}
+
 void Rig::driver(Slot *sp)
 {
     Slot &s = *sp;
@@ -556,32 +620,11 @@ void Rig::driver(Slot *sp)
         Job j;
         {
             std::unique_lock<std::mutex> lk(s.m);
-            s.cv.wait(lk, [&s] { return s.quit || s.busy; });
+            s.cv.wait(lk, [&s] { return s.quit || (s.busy && !s.inline_job); });
             if (s.quit) return;
             j = s.job;
         }
-        int st = MCORB_OK;
-        switch (j.kind) {
-        case Job::EXTRACT:
-            st = run_extract_phaseA(s, j);
-            if (st == MCORB_OK) st = run_select_and_describe(s, j, false);
-            break;
-        case Job::PROCESS:
-            st = run_extract_phaseA(s, j);
-            if (st == MCORB_OK) st = run_select_and_describe(s, j, true);
-            if (st == MCORB_OK) st = finish_match(s, j);
-            break;
-        case Job::MATCH:
-            st = enqueue_match(s, j, false);
-            if (st == MCORB_OK) {
-                hipError_t e = hipEventRecord(s.ev[10], s.st);
-                if (e == hipSuccess) e = hipEventSynchronize(s.ev[10]);
-                if (e != hipSuccess) { set_error(hipGetErrorString(e)); st = MCORB_E_HIP; }
-            }
-            if (st == MCORB_OK) st = finish_match(s, j);
-            break;
-        default: break;
-        }
+        const int st = execute(s, j);
         {
             std::lock_guard<std::mutex> lk(s.m);
             s.status = st;
@@ -629,6 +672,19 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     pool->parallel_for(nimg, [&](int m, int w) {
         HostProf::Scope prof_task(0);
         const int *lo = s.h_lvloff + (size_t)m * (kMaxLevels + 1);
+        {
+            // the GPU wrote these over PCIe, so they sit in DRAM, not in this core's caches: stream-prefetch them
+            // (candidates ~130 KB, bucket tables ~30 KB per image) instead of taking the misses one by one below
+            // (demand loads, one per line: software prefetches were measured slower, most get dropped)
+            uint32_t touch = 0;
+            const uint32_t *c = s.h_cand + (size_t)m * geom.candCap;
+            for (int i = 0, e = lo[L]; i < e; i += 16) touch += c[i];
+            const uint32_t *b1 = reinterpret_cast<const uint32_t *>(s.h_bstart + (size_t)m * geom.bucketTotal);
+            const uint32_t *b2 = reinterpret_cast<const uint32_t *>(s.h_bbest + (size_t)m * geom.bucketTotal);
+            for (int i = 0; i < geom.bucketTotal; i += 16) touch += b1[i];
+            for (int i = 0; i < 2 * geom.bucketTotal; i += 16) touch += b2[i];
+            s.touch_sink[m & 15] = touch;   // keeps the loads alive
+        }
         int total = 0;
         HostProf::Scope *prof_sel = new (alloca(sizeof(HostProf::Scope))) HostProf::Scope(1);
         for (int level = 0; level < L; level++) {
@@ -677,7 +733,7 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
         }
         s.mono[m] = monoIndex;
         s.h_nsel[m] = total;
-    });
+    }, pool_threads + s.index);
     if (bad.load() == 1) { set_error("selection failed: level too tall"); (void)hipStreamSynchronize(s.st); return MCORB_E_SIZE; }
     if (bad.load()) { set_error("keypoint capacity exceeded"); (void)hipStreamSynchronize(s.st); return MCORB_E_CAP; }
     const auto t1 = std::chrono::steady_clock::now();
@@ -722,7 +778,6 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
 // fills the host side of the control block for a match: per-(frame,cam) sets/counts and the pair list
 int Rig::prepare_match(Slot &s, const Job &j)
 {
-    HostProf::Scope prof(3);
     const bool ext = j.ext_desc != nullptr;
     if (j.nframes < 1 || j.nframes > max_frames || (!ext && j.nframes * ncams > s.nimg_done)) {
         set_error("match: bad frame count or features not extracted");
@@ -840,7 +895,7 @@ int Rig::finish_match(Slot &s, const Job &j)
     (void)j;
     HostProf::Scope prof(2);
     const int C = ncams;
-    for (int f = 0; f < s.nframes_done; f++) {
+    auto one_frame = [&](int f, int) {
         int pi = f * npp;
         for (int a = 0; a < C - 1; a++) {
             for (int b = a + 1; b < C; b++, pi++) {
@@ -855,7 +910,10 @@ int Rig::finish_match(Slot &s, const Job &j)
             }
         }
         merge_tracks(s, f, nullptr, s.tracks[f], s.mergeable[f]);
-    }
+    };
+    // frames are independent (own pair lists, own track table): one pool task each
+    if (s.nframes_done > 1) pool->parallel_for(s.nframes_done, one_frame, pool_threads + s.index);
+    else if (s.nframes_done == 1) one_frame(0, 0);
     if (s.npairs_done > 0) {
         float m = 0;
         (void)hipEventElapsedTime(&m, s.ev[7], s.ev[9]); s.timing[3] = m * 1000.f;

@@ -42,7 +42,8 @@ public:
     explicit WorkerPool(int nthreads);
     ~WorkerPool();
     // runs fn(task, worker_index) for task in [0, n); returns when all are done
-    void parallel_for(int n, const std::function<void(int, int)> &fn);
+    // caller_widx >= 0: the calling thread takes tasks as well, using that worker index
+    void parallel_for(int n, const std::function<void(int, int)> &fn, int caller_widx = -1);
     int size() const { return (int)threads_.size(); }
 
 private:
@@ -94,6 +95,7 @@ struct Slot {
     // host, device-mapped (kernels write/read these directly over PCIe)
     uint32_t *h_cand = nullptr;
     int *h_lvloff = nullptr, *h_overflow = nullptr, *h_bstart = nullptr;
+    volatile uint32_t touch_sink[16] = {};
     BucketBest *h_bbest = nullptr;   // per bucket: winner of the final pick (k_compact)
     KnnRow *h_knn = nullptr;
     // control block: one pinned host buffer + one device mirror, copied with a single
@@ -125,7 +127,7 @@ struct Slot {
     std::mutex m;
     std::condition_variable cv;
     Job job;
-    bool busy = false, quit = false;
+    bool busy = false, quit = false, inline_job = false;
     int status = MCORB_OK;
     std::string err;
 };
@@ -147,6 +149,7 @@ public:
     int upload_u8(int slot, const uint8_t *const *images, int nimg, int stride);
     int upload_f32(int slot, const float *const *images, int nimg, int stride_bytes, int channels);
     int submit(int slot, const Job &job);
+    int run_sync(int slot, const Job &job);   // submit + wait on the calling thread
     int wait(int slot);
 
     mcorb_params params;
@@ -159,12 +162,14 @@ public:
     int resize_win[2 * kMaxLevels] = {};   // per level: LDS window pitch, rows (see launch_pyramid)
     std::vector<Slot *> slots;
     WorkerPool *pool = nullptr;
+    int pool_threads = 0;
     std::vector<SelectScratch *> scratch;   // one per worker
 
     void merge_tracks(Slot &s, int f, const EpipolarGate *gate, std::vector<int32_t> &tr, int &mergeable_out) const;
 
 private:
     void driver(Slot *s);
+    int execute(Slot &s, const Job &j);
     int run_extract_phaseA(Slot &s, const Job &j);
     int run_select_and_describe(Slot &s, const Job &j, bool then_match);
     int prepare_match(Slot &s, const Job &j);

@@ -11,6 +11,7 @@
 
 #include "mcorb_common.h"
 #include "mcorb_kernels.h"
+#include <stdlib.h>
 
 namespace mcorb {
 
@@ -254,20 +255,29 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         return;
     }
 
-    // ---- stage the ROI in LDS with aligned dword loads (same byte phase as HBM) ----
+    // ---- stage the ROI in LDS, same byte phase as HBM: 16-byte chunks (4-byte aligned in HBM, 16-byte
+    //      aligned in LDS), two per lane per trip with both loads issued before the first store so that a
+    //      35-px cell costs one HBM round trip instead of eight ----
     const uint8_t *plane = pyr + (size_t)img * g.imgBytes + L.off;
     const int ph = iniX & 3;
-    const int nd = (ph + cols + 3) >> 2;   // dwords per row, <= 20
-    const int TP = nd * 4;                 // LDS pitch of this cell
+    const int nq = (ph + cols + 15) >> 4;   // 16-byte chunks per row, <= 3 for 35-px cells
+    const int nd = nq * 4;                  // dwords per LDS row
+    const int TP = nq * 16;                 // LDS pitch of this cell
     {
+        struct __attribute__((packed, aligned(4))) Chunk { uint32_t a, b, c, d; };
         const uint8_t *src0 = plane + (size_t)iniY * L.pitch + (iniX - ph);
-        uint32_t *t32 = reinterpret_cast<uint32_t *>(tile);
-        uint32_t *s32 = reinterpret_cast<uint32_t *>(sc);
-        const float rcp_nd = 1.0f / (float)nd;
-        for (int i = lane; i < rows * nd; i += 64) {
-            const int y = (int)(((float)i + 0.5f) * rcp_nd), d = i - y * nd;
-            s32[i] = 0;
-            t32[i] = *reinterpret_cast<const uint32_t *>(src0 + (size_t)y * L.pitch + 4 * d);
+        uint4 *t128 = reinterpret_cast<uint4 *>(tile);
+        uint4 *s128 = reinterpret_cast<uint4 *>(sc);
+        const int ntask = rows * nq;
+        const float rcp_nq = 1.0f / (float)nq;
+        for (int i0 = 0; i0 < ntask; i0 += 128) {
+            const int ia = i0 + lane, ib = i0 + 64 + lane;
+            const int ya = (int)(((float)ia + 0.5f) * rcp_nq), yb = (int)(((float)ib + 0.5f) * rcp_nq);
+            Chunk ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
+            if (ia < ntask) ca = *reinterpret_cast<const Chunk *>(src0 + (size_t)ya * L.pitch + 16 * (ia - ya * nq));
+            if (ib < ntask) cb = *reinterpret_cast<const Chunk *>(src0 + (size_t)yb * L.pitch + 16 * (ib - yb * nq));
+            if (ia < ntask) { t128[ia] = uint4{ca.a, ca.b, ca.c, ca.d}; s128[ia] = uint4{0, 0, 0, 0}; }
+            if (ib < ntask) { t128[ib] = uint4{cb.a, cb.b, cb.c, cb.d}; s128[ib] = uint4{0, 0, 0, 0}; }
         }
     }
     __syncthreads();   // single-wave workgroup: lowers to a wait, not an s_barrier
@@ -872,10 +882,9 @@ __device__ __forceinline__ uint32_t hamming256(const ulonglong4 &a, const ulongl
 
 __device__ __forceinline__ void knn_insert(uint32_t key, uint32_t &k0, uint32_t &k1)
 {
-    const uint32_t lo = key < k0 ? key : k0;
-    const uint32_t hi = key < k0 ? k0 : key;
+    const uint32_t hi = key > k0 ? key : k0;   // k0 <= k1 always: v_max, v_min, v_min
     k1 = hi < k1 ? hi : k1;
-    k0 = lo;
+    k0 = key < k0 ? key : k0;
 }
 
 // kKnnQpl queries per lane (q, q+64, ...): every broadcast LDS read of a train descriptor feeds
@@ -900,6 +909,8 @@ __global__ __launch_bounds__(64) void k_knn2(const uint8_t *__restrict__ desc, c
     for (int u = 0; u < kKnnQpl; u++) k0[u] = k1[u] = 0xffffffffu;
     if (t0 < nt) {
         const int tn = nt - t0 < kKnnChunk ? nt - t0 : kKnnChunk;
+        // (fetching the wave-uniform train descriptor with scalar loads instead of LDS broadcasts was measured
+        // slower: 125 vs 118 us -- the s_load latency is not hidden with four in flight per wave)
         const ulonglong4 *tsrc = reinterpret_cast<const ulonglong4 *>(desc + ((size_t)qt.y * kcap + t0) * 32);
         for (int i = lane; i < tn; i += 64) tr[i] = tsrc[i];
         __syncthreads();
@@ -1053,10 +1064,10 @@ void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, i
                  int *cell_cnt, int nimg)
 {
     dim3 grid(g.cells, nimg);
-    // LDS per cell: ROI rows x dword-aligned pitch (3 phase bytes + wCell + 6), for the tile and for the score map
+    // LDS per cell: ROI rows x 16-byte-aligned pitch (3 phase bytes + wCell + 6), for the tile and for the score map
     int tileBytes = 0;
     for (int l = 0; l < g.nlevels; l++) {
-        const int tb = (g.lv[l].hCell + 6) * (((3 + g.lv[l].wCell + 6 + 3) >> 2) << 2);
+        const int tb = (g.lv[l].hCell + 6) * (((3 + g.lv[l].wCell + 6 + 15) >> 4) << 4);
         tileBytes = tileBytes > tb ? tileBytes : tb;
     }
     tileBytes = (tileBytes + 15) & ~15;

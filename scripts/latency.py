@@ -22,8 +22,7 @@ def measure(mcorb, C=4, W=1280, H=720, N=2000, frames=200, distinct=8):
         t0 = time.perf_counter()
         rig.upload(imgs)
         t1 = time.perf_counter()
-        rig.process_submit(1)
-        rig.process_wait()
+        rig.process(1)
         t2 = time.perf_counter()
         feats = [rig.features(c) for c in range(C)]
         tr, _ = rig.tracks(0)
