@@ -86,6 +86,12 @@ void mcorb_rig_destroy(mcorb_rig *r);
  * level-0 planes through pinned buffers + hipMemcpyAsync.  Replaces the u8 end
  * of the hand-off (MultiCameraFrame.cpp:108-140). */
 int mcorb_rig_upload_u8(mcorb_rig *r, int slot, const uint8_t *const *images, int nimg, int stride);
+/* Zero-copy variant of the hand-off: the reader decodes straight into the slot's pinned staging buffer
+ * (image m: *ptr, W bytes per row, H rows) and mcorb_rig_upload_staged starts the DMA of images 0..nimg-1.
+ * This is the "pinned hipMemcpyAsync" staging of DatasetReader::loadNext's cv::imread target
+ * (MCDataUtils/src/DatasetReader.cpp:688-719) without the intermediate clone. */
+int mcorb_rig_staging(mcorb_rig *r, int slot, int m, uint8_t **ptr, int *stride);
+int mcorb_rig_upload_staged(mcorb_rig *r, int slot, int nimg);
 /* Same for the reference's staging format: CV_32F in [0,1], 1 or 3 (BGR)
  * channels (DatasetReader.cpp:699-712); x255, round-half-even, saturate and
  * BGR2GRAY run on the device. */

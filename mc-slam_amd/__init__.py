@@ -101,6 +101,16 @@ class Rig:
         return len(arrs)
 
     # -- extraction ---------------------------------------------------------
+    def staging(self, m, slot=0):
+        """The slot's pinned staging plane of image m as a writable (H, W) uint8 array (zero-copy hand-off)."""
+        ptr, stride = C.c_void_p(), C.c_int()
+        _lib.check(self.L.mcorb_rig_staging(self.h_rig, slot, m, C.byref(ptr), C.byref(stride)))
+        buf = (C.c_uint8 * (self.h * stride.value)).from_address(ptr.value)
+        return np.frombuffer(buf, np.uint8).reshape(self.h, stride.value)[:, :self.w]
+
+    def upload_staged(self, nimg, slot=0):
+        _lib.check(self.L.mcorb_rig_upload_staged(self.h_rig, slot, nimg))
+
     def extract(self, nimg, slot=0, lap=(0, 0)):
         _lib.check(self.L.mcorb_rig_extract(self.h_rig, slot, nimg, lap[0], lap[1]))
 

@@ -49,6 +49,8 @@ SIGNATURES = {
     "mcorb_rig_extract_submit": (_i, [_vp, _i, _i, _i, _i]),
     "mcorb_rig_extract_wait": (_i, [_vp, _i]),
     "mcorb_rig_extract": (_i, [_vp, _i, _i, _i, _i]),
+    "mcorb_rig_staging": (_i, [_vp, _i, _i, _vp, _ip]),
+    "mcorb_rig_upload_staged": (_i, [_vp, _i, _i]),
     "mcorb_rig_process_submit": (_i, [_vp, _i, _i, _i, _i, _f, _f]),
     "mcorb_rig_process": (_i, [_vp, _i, _i, _i, _i, _f, _f]),
     "mcorb_rig_process_wait": (_i, [_vp, _i]),

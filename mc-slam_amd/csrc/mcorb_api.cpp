@@ -88,6 +88,24 @@ int mcorb_rig_upload_u8(mcorb_rig *r, int slot, const uint8_t *const *images, in
     if (!r) return MCORB_E_ARG;
     return r->rig.upload_u8(slot, images, nimg, stride);
 }
+int mcorb_rig_staging(mcorb_rig *r, int slot, int m, uint8_t **ptr, int *stride)
+{
+    if (!r || slot < 0 || slot >= (int)r->rig.slots.size() || m < 0 || m >= r->rig.max_images || !ptr) { set_error("staging: bad argument"); return MCORB_E_ARG; }
+    Slot *s = r->rig.slots[slot];
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        if (s->busy) { set_error("slot busy"); return MCORB_E_STATE; }
+    }
+    if (hipStreamSynchronize(s->st) != hipSuccess) { set_error("staging: stream error"); return MCORB_E_HIP; }   // earlier DMA out of this buffer done
+    *ptr = s->h_stage + (size_t)m * r->rig.W * r->rig.H;
+    if (stride) *stride = r->rig.W;
+    return MCORB_OK;
+}
+int mcorb_rig_upload_staged(mcorb_rig *r, int slot, int nimg)
+{
+    if (!r) return MCORB_E_ARG;
+    return r->rig.upload_staged(slot, nimg);
+}
 int mcorb_rig_upload_f32(mcorb_rig *r, int slot, const float *const *images, int nimg, int stride_bytes, int channels)
 {
     if (!r) return MCORB_E_ARG;

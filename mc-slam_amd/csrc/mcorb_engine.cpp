@@ -396,10 +396,11 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         else HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&s->st_copy, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&s->st_dma, hipStreamNonBlocking));
-        // events a driver thread sleeps on (3 compaction, 10 compute stream, 11 DMA stream): with more than two slots
-        // the drivers would otherwise spin on as many cores as there are slots and starve the selection workers
+        // events a driver thread waits on (3 compaction, 10 compute stream, 11 DMA stream).  HIP spins by default, which
+        // measured 2-4 % faster than interrupt-driven waits at 6 slots; with many slots the spinning drivers would take
+        // the cores the selection workers need, so those rigs sleep instead.  MCORB_SYNC=block|spin overrides.
         const char *sync_env = getenv("MCORB_SYNC");
-        const bool blocking = sync_env ? !strcmp(sync_env, "block") : nslots > 2;
+        const bool blocking = sync_env ? !strcmp(sync_env, "block") : nslots > 8;
         for (int e = 0; e < 12; e++) {
             const bool waited = e == 3 || e == 10 || e == 11;
             HIPCHK(hipEventCreateWithFlags(&s->ev[e], waited && blocking ? hipEventBlockingSync : hipEventDefault));
@@ -496,13 +497,33 @@ int Rig::upload_u8(int slot, const uint8_t *const *images, int nimg, int stride)
     Slot &s = *slots[slot];
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamSynchronize(s.st));   // staging buffer free again
-    for (int m = 0; m < nimg; m++) {
+    for (int m = 0; m < nimg; m++)
         if (!images[m]) { set_error("upload_u8: empty image"); return MCORB_E_EMPTY; }
+    // pageable caller memory -> pinned staging buffer: one pool task per image (the calling thread takes its share)
+    auto copy_one = [&](int m, int) {
         uint8_t *dst = s.h_stage + (size_t)m * W * H;
         if (stride == W) memcpy(dst, images[m], (size_t)W * H);
         else for (int y = 0; y < H; y++) memcpy(dst + (size_t)y * W, images[m] + (size_t)y * stride, W);
-        HIPCHK(hipMemcpy2DAsync(s.d_pyr + (size_t)m * geom.imgBytes + geom.lv[0].off, geom.lv[0].pitch, dst, W, W, H,
-                                hipMemcpyHostToDevice, s.st));
+    };
+    if (nimg > 1) pool->parallel_for(nimg, copy_one, pool_threads + s.index);
+    else copy_one(0, 0);
+    return upload_staged(slot, nimg);
+}
+
+// DMA of the slot's pinned staging buffer (image m at m*W*H, row stride W) into level 0 of the pyramid planes.
+int Rig::upload_staged(int slot, int nimg)
+{
+    if (slot < 0 || slot >= (int)slots.size() || nimg < 1 || nimg > max_images) { set_error("upload_staged: bad argument"); return MCORB_E_ARG; }
+    Slot &s = *slots[slot];
+    HIPCHK(hipSetDevice(device));
+    const size_t plane = (size_t)W * H;
+    if (geom.lv[0].pitch == W) {
+        // level-0 rows are contiguous: the whole batch is one strided copy (one row = one image)
+        HIPCHK(hipMemcpy2DAsync(s.d_pyr + geom.lv[0].off, geom.imgBytes, s.h_stage, plane, plane, nimg, hipMemcpyHostToDevice, s.st));
+    } else {
+        for (int m = 0; m < nimg; m++)
+            HIPCHK(hipMemcpy2DAsync(s.d_pyr + (size_t)m * geom.imgBytes + geom.lv[0].off, geom.lv[0].pitch, s.h_stage + m * plane, W, W, H,
+                                    hipMemcpyHostToDevice, s.st));
     }
     return MCORB_OK;
 }

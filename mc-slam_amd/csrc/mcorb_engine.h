@@ -147,6 +147,7 @@ public:
     int init(const mcorb_params &p, int ncams, int W, int H, int max_frames, int nslots);
 
     int upload_u8(int slot, const uint8_t *const *images, int nimg, int stride);
+    int upload_staged(int slot, int nimg);
     int upload_f32(int slot, const float *const *images, int nimg, int stride_bytes, int channels);
     int submit(int slot, const Job &job);
     int run_sync(int slot, const Job &job);   // submit + wait on the calling thread

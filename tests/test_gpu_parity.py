@@ -385,3 +385,27 @@ def test_orientation_mode_ic_angle(mc):
     # tap offset on rare keypoints; require >= 99.5 % of descriptors identical and report the rest
     same = np.all(d1 == d2, axis=1)
     assert same.mean() >= 0.995, "only %.3f of rotated descriptors identical" % same.mean()
+
+
+def test_zero_copy_staging_equals_upload(mc):
+    """mcorb_rig_staging / mcorb_rig_upload_staged: decode straight into the pinned planes, same results."""
+    C, W, H = 2, 640, 480
+    imgs = [mc.synth_rig_frame(4, C, c, W, H) for c in range(C)]
+    rig = mc.Rig(C, W, H, 1, 1, nfeatures=800)
+    rig.upload(imgs)
+    rig.process(1)
+    ref = [rig.features(c) for c in range(C)]
+    tr_ref, _ = rig.tracks(0)
+    for c in range(C):
+        rig.staging(c)[:] = 0
+    rig.upload_staged(C)
+    rig.process(1)
+    assert len(rig.features(0)[1]) == 0                    # flat planes: nothing to detect
+    for c in range(C):
+        rig.staging(c)[:] = imgs[c]
+    rig.upload_staged(C)
+    rig.process(1)
+    for c in range(C):
+        assert_same_features(ref[c], rig.features(c), "staged cam %d" % c)
+    assert np.array_equal(rig.tracks(0)[0], tr_ref)
+    rig.close()
