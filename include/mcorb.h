@@ -268,8 +268,9 @@ int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_vocab *v, int l
 /* The engine's quad-tree selection, DistributeOctTree's equivalent (ORBextractor.cpp:554-778), run
  * end to end on the host: the candidate bucketing that k_compact performs on the device is
  * restated on the CPU, then the host tree logic runs on it.  packed = (y<<20 | x<<8 | response),
- * x/y relative to minBorder; wCell/hCell = cell grid of the detection loop, from which the
- * reference's "first maximum wins" order (cell row, cell col, y, x) is recovered (pass 0,0 when
+ * x/y relative to minBorder, in vToDistributeKeys order (the "first maximum wins" tie of the final
+ * pick follows the input order); wCell/hCell = cell grid of the detection loop, from which the same
+ * order (cell row, cell col, y, x) is recovered for nodes deeper than the bucketing (pass 0,0 when
  * the candidates are in plain raster order).  out_idx receives indices into `packed` in result
  * order.  Returns the count, MCORB_E_SIZE, or MCORB_E_CAP. */
 int mcorb_host_select(const uint32_t *packed, int n, int minX, int maxX, int minY, int maxY,

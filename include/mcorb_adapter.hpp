@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <array>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -176,6 +177,57 @@ public:
     IntraMatch() : mono(true), n_rays(0) { matchIndex.fill(-1); }
 };
 
+// ORBVocabulary = DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (ORBVocabulary.h:21-30), the members this path uses
+class ORBVocabulary {
+public:
+    typedef std::map<unsigned int, double> BowVector;                        // DBoW2::BowVector (WordId -> WordValue)
+    typedef std::map<unsigned int, std::vector<unsigned int>> FeatureVector; // DBoW2::FeatureVector (NodeId -> feature indices)
+    explicit ORBVocabulary(int device = 0) : device_(device) {}
+    ~ORBVocabulary() { mcorb_vocab_destroy(v_); }
+    ORBVocabulary(const ORBVocabulary &) = delete;
+    ORBVocabulary &operator=(const ORBVocabulary &) = delete;
+    // loadFromTextFile (FrontEnd.h:137-138): false when the file cannot be read or parsed
+    bool loadFromTextFile(const std::string &filename)
+    {
+        mcorb_vocab_destroy(v_);
+        v_ = nullptr;
+        return mcorb_vocab_load_text(filename.c_str(), device_, &v_) == MCORB_OK;
+    }
+    // nodes 1..nnodes in file order: parent id, leaf flag, 32-byte descriptor, weight
+    void create(int k, int L, int scoring, int weighting, const std::vector<int32_t> &parent, const std::vector<uint8_t> &is_leaf,
+                const std::vector<uint8_t> &desc, const std::vector<double> &weight)
+    {
+        mcorb_vocab_destroy(v_);
+        v_ = nullptr;
+        check(mcorb_vocab_create(k, L, scoring, weighting, parent.data(), is_leaf.data(), desc.data(), weight.data(), (int)parent.size(),
+                                 device_, &v_), "mcorb_vocab_create");
+    }
+    // transform(features, BowVector&, FeatureVector&, levelsup) on n packed 32-byte descriptors
+    void transform(const uint8_t *desc, int n, BowVector &v, FeatureVector &fv, int levelsup) const
+    {
+        std::vector<uint32_t> ids(n + 1), nodes(n + 1);
+        std::vector<double> vals(n + 1);
+        std::vector<int32_t> offs(n + 2), feats(n + 1);
+        int nb = 0, nf = 0;
+        check(mcorb_vocab_transform(v_, desc, n, levelsup, ids.data(), vals.data(), n + 1, &nb, nodes.data(), offs.data(), n + 1, &nf,
+                                    feats.data(), n + 1), "mcorb_vocab_transform");
+        fill(ids, vals, nb, nodes, offs, feats, nf, v, fv);
+    }
+    mcorb_vocab *handle() const { return v_; }
+    static void fill(const std::vector<uint32_t> &ids, const std::vector<double> &vals, int nb, const std::vector<uint32_t> &nodes,
+                     const std::vector<int32_t> &offs, const std::vector<int32_t> &feats, int nf, BowVector &v, FeatureVector &fv)
+    {
+        v.clear(); fv.clear();
+        for (int i = 0; i < nb; i++) v.emplace_hint(v.end(), ids[i], vals[i]);
+        for (int i = 0; i < nf; i++)
+            fv.emplace_hint(fv.end(), nodes[i], std::vector<unsigned int>(feats.begin() + offs[i], feats.begin() + offs[i + 1]));
+    }
+
+private:
+    int device_;
+    mcorb_vocab *v_ = nullptr;
+};
+
 // The extract + intra-rig-match members of MultiCameraFrame for one rig frame.
 class MultiCameraFrontEnd {
 public:
@@ -262,6 +314,39 @@ public:
             }
     }
 #endif
+    // computeIntraMatches(matches, words_) (MultiCameraFrame.cpp:586-943), the variant FrontEnd.cpp:1009 calls;
+    // levelsup as in extractFeatureSingle's transform call (:257)
+    void computeIntraMatches(std::vector<IntraMatch> &matches, std::vector<unsigned int> &words_, const ORBVocabulary &voc,
+                             double max_neighbor_ratio = 0.85, int levelsup = 4)
+    {
+        const int cap = mcorb_rig_kcap(rig_) * num_cams_;
+        std::vector<int32_t> tr((size_t)cap * num_cams_), rays(cap);
+        std::vector<uint32_t> w(cap);
+        int n = 0, nw = 0;
+        check(mcorb_rig_match_bow(rig_, 0, 0, voc.handle(), levelsup, max_neighbor_ratio, tr.data(), rays.data(), cap, &n, w.data(), cap, &nw),
+              "mcorb_rig_match_bow");
+        matches.clear();
+        matches.resize(n);
+        for (int m = 0; m < n; m++) {
+            for (int c = 0; c < num_cams_; c++) matches[m].matchIndex[c] = tr[(size_t)m * num_cams_ + c];
+            matches[m].n_rays = rays[m];
+        }
+        words_.insert(words_.end(), w.begin(), w.begin() + nw);
+    }
+    // orb_vocabulary->transform(image_descriptors[cam], BoW_vecs[cam], BoW_feats[cam], levelsup) (MultiCameraFrame.cpp:257),
+    // reading the descriptors where extraction left them on the device
+    void transform(int cam, const ORBVocabulary &voc, ORBVocabulary::BowVector &bow, ORBVocabulary::FeatureVector &fv, int levelsup = 4)
+    {
+        const int n = (int)image_kps[cam].size();
+        std::vector<uint32_t> ids(n + 1), nodes(n + 1);
+        std::vector<double> vals(n + 1);
+        std::vector<int32_t> offs(n + 2), feats(n + 1);
+        int nb = 0, nf = 0;
+        check(mcorb_rig_transform_image(rig_, 0, cam, voc.handle(), levelsup, ids.data(), vals.data(), n + 1, &nb, nodes.data(), offs.data(),
+                                        n + 1, &nf, feats.data(), n + 1), "mcorb_rig_transform_image");
+        ORBVocabulary::fill(ids, vals, nb, nodes, offs, feats, nf, bow, fv);
+    }
+
     // image_kps_undist for the epipolar check; by default the extracted keypoints are used (RECTIFY=false)
     void setUndistorted(const std::vector<std::vector<mcorb_keypoint>> &kps_undist) { image_kps_undist = kps_undist; }
 

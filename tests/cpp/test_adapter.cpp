@@ -79,6 +79,28 @@ int main(int argc, char **argv)
         uint64_t he = 1469598103934665603ULL;
         for (auto &m : matches) he = fnv(he, m.matchIndex.data(), (size_t)C * sizeof(int));
         printf("epipolar tracks=%zu/%016llx mergeable=%d\n", matches.size(), (unsigned long long)he, fr.cnt_mergable_matches);
+
+        // computeIntraMatches(matches, words_) + transform() with a vocabulary text file (argv[6], optional)
+        if (argc > 6) {
+            mcorb::ORBVocabulary voc;
+            if (!voc.loadFromTextFile(argv[6])) throw std::runtime_error("vocabulary did not load");
+            std::vector<unsigned int> words_;
+            fr.computeIntraMatches(matches, words_, voc, 0.85, 2);
+            uint64_t hb = 1469598103934665603ULL;
+            for (auto &m : matches) {
+                hb = fnv(hb, m.matchIndex.data(), (size_t)C * sizeof(int));
+                hb = fnv(hb, &m.n_rays, sizeof(int));
+            }
+            hb = fnv(hb, words_.data(), words_.size() * sizeof(unsigned int));
+            mcorb::ORBVocabulary::BowVector bow;
+            mcorb::ORBVocabulary::FeatureVector fv;
+            fr.transform(0, voc, bow, fv, 2);
+            uint64_t hv = 1469598103934665603ULL;
+            for (auto &e : bow) { hv = fnv(hv, &e.first, 4); hv = fnv(hv, &e.second, 8); }
+            for (auto &e : fv) { hv = fnv(hv, &e.first, 4); hv = fnv(hv, e.second.data(), e.second.size() * 4); }
+            printf("bow tracks=%zu words=%zu hash=%016llx transform=%zu/%zu/%016llx\n", matches.size(), words_.size(),
+                   (unsigned long long)hb, bow.size(), fv.size(), (unsigned long long)hv);
+        }
     } catch (const std::exception &e) {
         fprintf(stderr, "FAILED: %s\n", e.what());
         return 1;

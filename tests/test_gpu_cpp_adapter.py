@@ -38,7 +38,11 @@ def test_cpp_adapter_matches_oracle():
     import mcorb
     build_exe()
     C, W, H, N, frame = 3, 640, 480, 1000, 1
-    out = subprocess.run([EXE, str(C), str(W), str(H), str(N), str(frame)], capture_output=True, text=True, timeout=120)
+    vocab = O.make_vocabulary(10, 3, seed=5)
+    vpath = os.path.join(ROOT, "tests", "cpp", "_vocab_test.txt")
+    O.write_vocabulary_text(vocab, vpath)
+    out = subprocess.run([EXE, str(C), str(W), str(H), str(N), str(frame), vpath], capture_output=True, text=True, timeout=120)
+    os.remove(vpath)
     assert out.returncode == 0, out.stderr
     lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines() if " " in l)
     imgs = [mcorb.synth_rig_frame(frame, C, c, W, H) for c in range(C)]
@@ -69,3 +73,20 @@ def test_cpp_adapter_matches_oracle():
     for row in tr:
         he = fnv(he, row.astype(np.int32).tobytes())
     assert lines["epipolar"].strip() == "tracks=%d/%016x mergeable=%d" % (len(tr), he, mg)
+    # BoW-guided matcher and transform() through the C++ mirror, vocabulary read from its text file
+    fvs, bows = [], []
+    for o in ora:
+        b, f = O.bow_transform(vocab, o[2], 2)
+        bows.append(b); fvs.append(f)
+    tr, nr, words = O.intra_matches_bow([o[2] for o in ora], [o[1]["y"] for o in ora], fvs)
+    hb = F0
+    for row, n in zip(tr, nr):
+        hb = fnv(fnv(hb, row.astype(np.int32).tobytes()), np.int32(n).tobytes())
+    hb = fnv(hb, words.astype(np.uint32).tobytes())
+    hv = F0
+    for i, v in zip(*bows[0]):
+        hv = fnv(fnv(hv, np.uint32(i).tobytes()), np.float64(v).tobytes())
+    for node in sorted(fvs[0]):
+        hv = fnv(fnv(hv, np.uint32(node).tobytes()), fvs[0][node].astype(np.uint32).tobytes())
+    assert lines["bow"].strip() == "tracks=%d words=%d hash=%016x transform=%d/%d/%016x" % (
+        len(tr), len(words), hb, len(bows[0][0]), len(fvs[0]), hv)

@@ -56,10 +56,14 @@ def _content(kind, W=800, H=600):
         base = np.add.outer(np.arange(H), np.arange(W)) * 255 // (H + W)
         base[100:104, 100:104] = 255
         base[300:303, 500:503] = 0
+    elif kind == "clustered":       # every corner inside two small patches: the quad-tree goes far deeper than the GPU bucketing
+        base = np.full((H, W), 128, np.int64)
+        base[200:330, 420:560] = rng.integers(0, 256, (130, 140))
+        base[60:110, 80:150] = rng.integers(0, 2, (50, 70)) * 255
     return np.clip(base, 0, 255).astype(np.uint8)
 
 
-@pytest.mark.parametrize("kind", ["low_contrast", "noise", "saturated", "gradient"])
+@pytest.mark.parametrize("kind", ["low_contrast", "noise", "saturated", "gradient", "clustered"])
 def test_image_content(mc, kind):
     img = _content(kind)
     ref = O.OracleExtractor(1000)(img)

@@ -86,6 +86,26 @@ def test_selection_stage_matches_oracle_on_random_candidates(seed, W, H, N, npts
     assert np.array_equal(idx_p, idx_o), "selection differs in content or ORDER"
 
 
+@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("W,H,N,npts,box", [(1280, 720, 434, 3000, 90), (640, 480, 217, 2500, 60), (1280, 720, 434, 6000, 200)])
+def test_selection_stage_on_clustered_candidates(seed, W, H, N, npts, box):
+    """All corners inside one small square (+ a few strays): the tree has to go several levels deeper than the
+    GPU bucketing, i.e. the host partitions and scans keys itself -- and must agree with the bucket winners on
+    the "first maximum in vToDistributeKeys order" tie rule (few distinct responses => many ties)."""
+    rng = np.random.default_rng(100 + seed)
+    bx, by = rng.integers(0, W - 32 - box), rng.integers(0, H - 32 - box)
+    cells = rng.permutation(box * box)[:min(npts, box * box)]
+    x = np.concatenate([bx + cells % box, rng.integers(0, W - 32, 25)]).astype(np.int32)
+    y = np.concatenate([by + cells // box, rng.integers(0, H - 32, 25)]).astype(np.int32)
+    _, uniq = np.unique(y.astype(np.int64) * 4096 + x, return_index=True)
+    x, y = x[uniq], y[uniq]                                  # unique pixels, raster order
+    r = rng.integers(20, 24, len(x)).astype(np.int32)
+    n_o, idx_o = O.distribute_octree(x.astype(np.float32), y.astype(np.float32), r.astype(np.float32),
+                                     16, W - 16, 16, H - 16, N)
+    n_p, idx_p = _select(x, y, r, W, H, N)
+    assert n_p == n_o and np.array_equal(idx_p, idx_o)
+
+
 def test_selection_stage_on_real_fast_candidates():
     synth = import_module("mc-slam_amd.synth")
     img = synth.synth_rig_frame_numpy(1, 2, 1, 640, 480)
