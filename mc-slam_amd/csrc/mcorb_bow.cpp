@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <fstream>
+#include <chrono>
 #include <map>
 #include <sstream>
 #include <string>
@@ -43,15 +44,21 @@ struct mcorb_vocab {
     uint8_t *d_child_desc = nullptr;
     // scratch for host-array transforms
     uint8_t *d_desc = nullptr;
-    int2 *d_out = nullptr, *h_out = nullptr;
+    int *d_word_id = nullptr; double *d_weight = nullptr;
+    mcorb::BowRes *d_out = nullptr, *h_out = nullptr;
     int cap = 0;
+    // scratch of mcorb_rig_match_bow (grow-only): device index tables + result table, pinned host mirror
+    int *d_mi = nullptr; float *d_my = nullptr; int2 *d_mrg = nullptr; int4 *d_mtab = nullptr, *h_mtab = nullptr;
+    size_t mi_cap = 0, my_cap = 0, mrg_cap = 0, mtab_cap = 0;
 };
 
 static void free_vocab(mcorb_vocab *v)
 {
     if (!v) return;
     (void)hipFree(v->d_child_start); (void)hipFree(v->d_child_count); (void)hipFree(v->d_child_id);
-    (void)hipFree(v->d_child_desc); (void)hipFree(v->d_desc); (void)hipFree(v->d_out);
+    (void)hipFree(v->d_child_desc); (void)hipFree(v->d_desc); (void)hipFree(v->d_out); (void)hipFree(v->d_word_id); (void)hipFree(v->d_weight);
+    (void)hipFree(v->d_mi); (void)hipFree(v->d_my); (void)hipFree(v->d_mrg); (void)hipFree(v->d_mtab);
+    if (v->h_mtab) (void)hipHostFree(v->h_mtab);
     if (v->h_out) (void)hipHostFree(v->h_out);
     delete v;
 }
@@ -114,27 +121,40 @@ static int build_vocab(int k, int L, int scoring, int weighting, const int32_t *
     HIPCHK(hipMemcpy(v->d_child_count, v->child_count.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(v->d_child_id, child_id.data(), child_id.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(v->d_child_desc, child_desc.data(), child_desc.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void **)&v->d_word_id, (size_t)(n + 1) * sizeof(int)));
+    HIPCHK(hipMalloc((void **)&v->d_weight, (size_t)(n + 1) * sizeof(double)));
+    HIPCHK(hipMemcpy(v->d_word_id, v->word_id.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(v->d_weight, v->weight.data(), (size_t)(n + 1) * sizeof(double), hipMemcpyHostToDevice));
     *out = v;
     return MCORB_OK;
 }
 
-// BowVector::addWeight / addIfNotExist / normalize and FeatureVector::addFeature, on std::map like DBoW2
-static void assemble(const mcorb_vocab *v, const int2 *res, int n, std::map<uint32_t, double> &bow,
+// BowVector::addWeight / addIfNotExist / normalize and FeatureVector::addFeature.  DBoW2 keeps both in std::maps;
+// the BowVector here is the equivalent sorted (word id, value) list: entries are gathered in feature order, stably
+// sorted by id and folded left to right, so every sum adds its terms in the order addWeight would have (bit-identical
+// doubles) and addIfNotExist keeps the first.
+typedef std::vector<std::pair<uint32_t, double>> BowList;
+static void assemble(const mcorb_vocab *v, const mcorb::BowRes *res, int n, BowList &bow,
                      std::map<uint32_t, std::vector<int32_t>> &fv)
 {
     const bool tf_like = v->weighting == 0 || v->weighting == 1;   // TF_IDF, TF
+    BowList raw;
+    raw.reserve(n);
     for (int i = 0; i < n; i++) {
-        const int node = res[i].x;
-        const uint32_t id = (uint32_t)v->word_id[node];
-        const double w = v->weight[node];
+        const double w = res[i].weight;   // looked up on the device: the host never touches the 1 M-entry tables
         if (w > 0) {   // not stopped
-            auto it = bow.lower_bound(id);
-            if (it != bow.end() && !(id < it->first)) {
-                if (tf_like) it->second += w;          // addWeight
-            } else {
-                bow.insert(it, std::make_pair(id, w));   // addWeight / addIfNotExist
-            }
-            fv[(uint32_t)res[i].y].push_back(i);
+            raw.emplace_back((uint32_t)res[i].word, w);
+            fv[(uint32_t)res[i].nodeup].push_back(i);
+        }
+    }
+    std::stable_sort(raw.begin(), raw.end(), [](const std::pair<uint32_t, double> &a, const std::pair<uint32_t, double> &b) { return a.first < b.first; });
+    bow.clear();
+    bow.reserve(raw.size());
+    for (const auto &e : raw) {
+        if (!bow.empty() && bow.back().first == e.first) {
+            if (tf_like) bow.back().second += e.second;   // addWeight on an existing word
+        } else {
+            bow.push_back(e);                             // addWeight / addIfNotExist on a new one
         }
     }
     // mustNormalize: L1_NORM, CHI_SQUARE, KL, BHATTACHARYYA -> L1; L2_NORM -> L2; DOT_PRODUCT -> none
@@ -156,7 +176,7 @@ static void assemble(const mcorb_vocab *v, const int2 *res, int n, std::map<uint
     }
 }
 
-static int emit(const std::map<uint32_t, double> &bow, const std::map<uint32_t, std::vector<int32_t>> &fv, uint32_t *bow_ids,
+static int emit(const BowList &bow, const std::map<uint32_t, std::vector<int32_t>> &fv, uint32_t *bow_ids,
                 double *bow_vals, int bow_cap, int *nbow, uint32_t *fv_nodes, int32_t *fv_offsets, int fv_cap, int *nfv,
                 int32_t *fv_feats, int feat_cap)
 {
@@ -187,8 +207,8 @@ static int ensure_scratch(mcorb_vocab *v, int n)
     v->d_desc = nullptr; v->d_out = nullptr; v->h_out = nullptr; v->cap = 0;
     const int cap = (n + 1023) / 1024 * 1024;
     HIPCHK(hipMalloc((void **)&v->d_desc, (size_t)cap * 32));
-    HIPCHK(hipMalloc((void **)&v->d_out, (size_t)cap * sizeof(int2)));
-    HIPCHK(hipHostMalloc((void **)&v->h_out, (size_t)cap * sizeof(int2), hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&v->d_out, (size_t)cap * sizeof(mcorb::BowRes)));
+    HIPCHK(hipHostMalloc((void **)&v->h_out, (size_t)cap * sizeof(mcorb::BowRes), hipHostMallocDefault));
     v->cap = cap;
     return MCORB_OK;
 }
@@ -254,13 +274,13 @@ static int transform_device(mcorb_vocab *v, const uint8_t *d_desc, int n, int le
                             double *bow_vals, int bow_cap, int *nbow, uint32_t *fv_nodes, int32_t *fv_offsets, int fv_cap,
                             int *nfv, int32_t *fv_feats, int feat_cap)
 {
-    std::map<uint32_t, double> bow;
+    BowList bow;
     std::map<uint32_t, std::vector<int32_t>> fv;
     if (n > 0) {
         const int nid_level = v->L - levelsup;   // <= 0: the feature vector is keyed by the root (node 0)
-        launch_bow_descend(st, d_desc, n, v->d_child_start, v->d_child_count, v->d_child_desc, v->d_child_id, nid_level, v->d_out);
+        launch_bow_descend(st, d_desc, n, v->d_child_start, v->d_child_count, v->d_child_desc, v->d_child_id, v->d_word_id, v->d_weight, nid_level, v->d_out);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(v->h_out, v->d_out, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(v->h_out, v->d_out, (size_t)n * sizeof(mcorb::BowRes), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         assemble(v, v->h_out, n, bow, fv);
     }
@@ -315,7 +335,7 @@ extern "C" int mcorb_rig_transform_image(mcorb_rig *r, int slot, int m, mcorb_vo
 // bookkeeping (new track / extend / merge into an existing one / override), replayed on that table.
 // ---------------------------------------------------------------------------
 namespace {
-struct BowTrack { std::vector<int> matchIndex; int n_rays; };
+struct BowTrack { int matchIndex[MCORB_MAX_CAMS]; int n_rays; };
 }
 
 extern "C" int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_vocab *v, int levelsup, double max_neighbor_ratio,
@@ -337,26 +357,40 @@ extern "C" int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_voca
     HIPCHK(hipSetDevice(R.device));
     const int TH_LOW = 75;   // ORBextractor.h:27
 
-    // 1. FeatureVector of every camera (transform(..., levelsup), MultiCameraFrame.cpp:257)
+    static const bool prof = getenv("MCORB_HOST_PROF") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    const auto T0 = now();
+    auto T1 = T0, T2 = T0, T3 = T0, T4 = T0;
+    // 1. FeatureVector of every camera (transform(..., levelsup), MultiCameraFrame.cpp:257): all descents are
+    //    queued back to back, one read-back, one synchronisation
     std::vector<std::map<uint32_t, std::vector<int32_t>>> fvs(C);
     std::vector<int> nfeat(C);
-    for (int c = 0; c < C; c++) {
-        const int m = frame * C + c, n = s->h_nsel[m];
-        nfeat[c] = n;
-        int st = ensure_scratch(v, std::max(n, 1));
+    {
+        int st = ensure_scratch(v, C * kcap);
         if (st != MCORB_OK) return st;
-        if (n > 0) {
-            launch_bow_descend(s->st, s->d_desc + (size_t)m * kcap * 32, n, v->d_child_start, v->d_child_count, v->d_child_desc,
-                               v->d_child_id, v->L - levelsup, v->d_out);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipMemcpyAsync(v->h_out, v->d_out, (size_t)n * sizeof(int2), hipMemcpyDeviceToHost, s->st));
-            HIPCHK(hipStreamSynchronize(s->st));
-            std::map<uint32_t, double> bow;
-            assemble(v, v->h_out, n, bow, fvs[c]);
+        for (int c = 0; c < C; c++) {
+            const int m = frame * C + c, n = s->h_nsel[m];
+            nfeat[c] = n;
+            if (n > 0)
+                launch_bow_descend(s->st, s->d_desc + (size_t)m * kcap * 32, n, v->d_child_start, v->d_child_count, v->d_child_desc,
+                                   v->d_child_id, v->d_word_id, v->d_weight, v->L - levelsup, v->d_out + (size_t)c * kcap);
         }
-        if (fvs[c].empty()) return MCORB_OK;   // the reference returns with no matches (:602-603)
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(v->h_out, v->d_out, (size_t)C * kcap * sizeof(mcorb::BowRes), hipMemcpyDeviceToHost, s->st));
+        HIPCHK(hipStreamSynchronize(s->st));
+        T1 = now();
+        for (int c = 0; c < C; c++) {
+            // FeatureVector only (addFeature for every non-stopped word, in feature order); the BowVector half of
+            // transform() is not needed here and its 2000 map insertions would dominate the call
+            const mcorb::BowRes *res = v->h_out + (size_t)c * kcap;
+            for (int i = 0; i < nfeat[c]; i++)
+                if (res[i].weight > 0) fvs[c][(uint32_t)res[i].nodeup].push_back(i);
+            if (fvs[c].empty()) return MCORB_OK;   // the reference returns with no matches (:602-603)
+        }
     }
 
+    T2 = now();
     // 2. node slots (distinct node ids over all cameras) and per-(slot, camera) feature ranges
     std::map<uint32_t, int> slot_id;
     for (int c = 0; c < C; c++)
@@ -378,41 +412,51 @@ extern "C" int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_voca
         for (size_t k = 0; k < K.size(); k++) yv[(size_t)c * kcap + k] = K[k].y;   // image_kps_undist[c][k].pt.y
     }
 
-    // 3. best / second-best table on the GPU
-    int *d_i = nullptr;
-    float *d_y = nullptr;
-    int2 *d_rg = nullptr;
-    int4 *d_tab = nullptr;
+    T3 = now();
+    // 3. best / second-best table on the GPU (scratch lives in the vocabulary object, grow-only)
     const size_t n_i = (size_t)C * kcap * 2 + C * 2, tab_n = (size_t)C * kcap * C;
-    HIPCHK(hipMalloc((void **)&d_i, n_i * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&d_y, yv.size() * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&d_rg, std::max<size_t>(node_range.size(), 1) * sizeof(int2)));
-    HIPCHK(hipMalloc((void **)&d_tab, tab_n * sizeof(int4)));
-    int *d_slot_of = d_i, *d_node_feats = d_i + (size_t)C * kcap, *d_sets = d_i + (size_t)C * kcap * 2, *d_nfeat = d_sets + C;
-    std::vector<int4> tab(tab_n);
-    int rc = MCORB_OK;
-    do {
-#define CK(x) if ((x) != hipSuccess) { set_error(#x); rc = MCORB_E_HIP; break; }
-        CK(hipMemcpyAsync(d_slot_of, slot_of.data(), slot_of.size() * sizeof(int), hipMemcpyHostToDevice, s->st));
-        CK(hipMemcpyAsync(d_node_feats, node_feats.data(), node_feats.size() * sizeof(int), hipMemcpyHostToDevice, s->st));
-        CK(hipMemcpyAsync(d_sets, sets.data(), C * sizeof(int), hipMemcpyHostToDevice, s->st));
-        CK(hipMemcpyAsync(d_nfeat, nfeat.data(), C * sizeof(int), hipMemcpyHostToDevice, s->st));
-        CK(hipMemcpyAsync(d_y, yv.data(), yv.size() * sizeof(float), hipMemcpyHostToDevice, s->st));
-        if (!node_range.empty()) CK(hipMemcpyAsync(d_rg, node_range.data(), node_range.size() * sizeof(int2), hipMemcpyHostToDevice, s->st));
-        launch_bow_best2(s->st, s->d_desc, d_sets, kcap, C, d_y, d_slot_of, d_rg, d_node_feats, d_nfeat, d_tab);
-        CK(hipGetLastError());
-        CK(hipMemcpyAsync(tab.data(), d_tab, tab_n * sizeof(int4), hipMemcpyDeviceToHost, s->st));
-        CK(hipStreamSynchronize(s->st));
-#undef CK
-    } while (0);
-    (void)hipFree(d_i); (void)hipFree(d_y); (void)hipFree(d_rg); (void)hipFree(d_tab);
-    if (rc != MCORB_OK) return rc;
+    auto grow = [](void **p, size_t &cap, size_t need, size_t elem) -> bool {
+        if (need <= cap) return true;
+        (void)hipFree(*p);
+        *p = nullptr; cap = 0;
+        if (hipMalloc(p, need * elem) != hipSuccess) return false;
+        cap = need;
+        return true;
+    };
+    if (!grow((void **)&v->d_mi, v->mi_cap, n_i, sizeof(int)) || !grow((void **)&v->d_my, v->my_cap, yv.size(), sizeof(float)) ||
+        !grow((void **)&v->d_mrg, v->mrg_cap, std::max<size_t>(node_range.size(), 1), sizeof(int2))) {
+        set_error("match_bow: device allocation failed");
+        return MCORB_E_HIP;
+    }
+    if (tab_n > v->mtab_cap) {
+        (void)hipFree(v->d_mtab);
+        if (v->h_mtab) (void)hipHostFree(v->h_mtab);
+        v->d_mtab = nullptr; v->h_mtab = nullptr; v->mtab_cap = 0;
+        HIPCHK(hipMalloc((void **)&v->d_mtab, tab_n * sizeof(int4)));
+        HIPCHK(hipHostMalloc((void **)&v->h_mtab, tab_n * sizeof(int4), hipHostMallocDefault));
+        v->mtab_cap = tab_n;
+    }
+    int *d_slot_of = v->d_mi, *d_node_feats = v->d_mi + (size_t)C * kcap, *d_sets = v->d_mi + (size_t)C * kcap * 2, *d_nfeat = d_sets + C;
+    HIPCHK(hipMemcpyAsync(d_slot_of, slot_of.data(), slot_of.size() * sizeof(int), hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(d_node_feats, node_feats.data(), node_feats.size() * sizeof(int), hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(d_sets, sets.data(), C * sizeof(int), hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(d_nfeat, nfeat.data(), C * sizeof(int), hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(v->d_my, yv.data(), yv.size() * sizeof(float), hipMemcpyHostToDevice, s->st));
+    if (!node_range.empty())
+        HIPCHK(hipMemcpyAsync(v->d_mrg, node_range.data(), node_range.size() * sizeof(int2), hipMemcpyHostToDevice, s->st));
+    launch_bow_best2(s->st, s->d_desc, d_sets, kcap, C, v->d_my, d_slot_of, v->d_mrg, d_node_feats, d_nfeat, v->d_mtab);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(v->h_mtab, v->d_mtab, tab_n * sizeof(int4), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));   // also covers the pageable host vectors above
+    const int4 *tab = v->h_mtab;
+    T4 = now();
 
     // 4. the reference's serial walk over common nodes (:647-929), reading best/second-best from the table
     typedef std::map<uint32_t, std::vector<int32_t>>::const_iterator It;
     std::vector<It> it(C), last(C);
     for (int c = 0; c < C; c++) { it[c] = fvs[c].begin(); last[c] = std::prev(fvs[c].end()); }
     std::vector<BowTrack> matches;
+    matches.reserve(10000);   // (:587)
     std::vector<uint32_t> words_;
     int intraMatchInd = 0;
     const uint8_t *hd = s->h_desc;
@@ -440,7 +484,7 @@ extern "C" int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_voca
                     bool foundMatch = false;
                     if (matchedFlags[i][a] != -1) continue;
                     BowTrack temp;
-                    temp.matchIndex.assign(C, -1);
+                    for (int tt = 0; tt < C; tt++) temp.matchIndex[tt] = -1;
                     temp.matchIndex[cam1] = feat_cam1[a];
                     temp.n_rays = 1;
                     matches.push_back(temp);
@@ -467,7 +511,8 @@ extern "C" int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_voca
                                     if (updateOnce) updateOnce = false;
                                     else continue;
                                     bool update_match = true;
-                                    std::vector<int> tmp = matches[existing].matchIndex;
+                                    int tmp[MCORB_MAX_CAMS];
+                                    for (int tt = 0; tt < C; tt++) tmp[tt] = matches[existing].matchIndex[tt];
                                     int inc = 0;
                                     for (int tt = 0; tt < C; tt++) {
                                         if (matches[intraMatchInd].matchIndex[tt] != -1) {
@@ -477,7 +522,7 @@ extern "C" int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_voca
                                         }
                                     }
                                     if (update_match) {
-                                        matches[existing].matchIndex = tmp;
+                                        for (int tt = 0; tt < C; tt++) matches[existing].matchIndex[tt] = tmp[tt];
                                         matches[existing].n_rays += inc;
                                         matchedFlags[i][a] = existing;
                                         intraMatchInd = existing;
@@ -510,6 +555,9 @@ extern "C" int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_voca
         }
         for (int c : selected) ++it[c];
     }
+    if (prof)
+        fprintf(stderr, "[mcorb host prof] match_bow: descend+sync %.0f us, assemble %.0f, tables %.0f, best2+copy %.0f, replay %.0f\n",
+                us(T0, T1), us(T1, T2), us(T2, T3), us(T3, T4), us(T4, now()));
     if (ntracks_out) *ntracks_out = (int)matches.size();
     if (nwords_out) *nwords_out = (int)words_.size();
     if ((int)matches.size() > cap_tracks || (words && (int)words_.size() > cap_words)) { set_error("match_bow: output too small"); return MCORB_E_CAP; }

@@ -26,6 +26,10 @@ __host__ __device__ inline int cand_resp(uint32_t p) { return (int)(p & 0xffu); 
 constexpr int kPickOrderMask = (1 << 23) - 1;
 struct BucketBest { uint32_t key, pos; };
 
+// result of the vocabulary descent of one descriptor: word id and weight of the leaf it reached (word < 0 never
+// happens for a well-formed tree), and the node id `levelsup` levels above the leaves (FeatureVector key)
+struct BowRes { int32_t word, nodeup; double weight; };
+
 // Packed selected keypoint handed back to the device: level (4) | y (14) | x (14), level coordinates.
 __host__ __device__ inline uint32_t pack_sel(int level, int x, int y) { return ((uint32_t)level << 28) | ((uint32_t)y << 14) | (uint32_t)x; }
 

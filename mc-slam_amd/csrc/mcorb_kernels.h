@@ -35,6 +35,7 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
 void launch_bow_best2(hipStream_t st, const uint8_t *desc, const int *sets, int kcap, int ncams, const float *yv,
                       const int *slot_of, const int2 *node_range, const int *node_feats, const int *nfeat, int4 *out);
 void launch_bow_descend(hipStream_t st, const uint8_t *desc, int n, const int *child_start, const int *child_count,
-                        const void *child_desc, const int *child_id, int nid_level, int2 *out);
+                        const void *child_desc, const int *child_id, const int *word_id, const double *weight, int nid_level,
+                        BowRes *out);
 
 }  // namespace mcorb

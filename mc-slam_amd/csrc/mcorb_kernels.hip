@@ -984,7 +984,8 @@ __global__ __launch_bounds__(256) void k_knn2_finalize(const uint2 *__restrict__
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_bow_descend(const uint8_t *__restrict__ desc, int n, const int *__restrict__ child_start,
                                                      const int *__restrict__ child_count, const ulonglong4 *__restrict__ child_desc,
-                                                     const int *__restrict__ child_id, int nid_level, int2 *__restrict__ out)
+                                                     const int *__restrict__ child_id, const int *__restrict__ word_id,
+                                                     const double *__restrict__ weight, int nid_level, BowRes *__restrict__ out)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1004,7 +1005,7 @@ __global__ __launch_bounds__(256) void k_bow_descend(const uint8_t *__restrict__
         if (level == nid_level) nid = node;
         cc = child_count[node];
     }
-    out[i] = int2{node, nid};
+    out[i] = BowRes{word_id[node], nid, weight[node]};
 }
 
 // ---------------------------------------------------------------------------
@@ -1128,11 +1129,12 @@ void launch_bow_best2(hipStream_t st, const uint8_t *desc, const int *sets, int 
 }
 
 void launch_bow_descend(hipStream_t st, const uint8_t *desc, int n, const int *child_start, const int *child_count,
-                        const void *child_desc, const int *child_id, int nid_level, int2 *out)
+                        const void *child_desc, const int *child_id, const int *word_id, const double *weight, int nid_level,
+                        BowRes *out)
 {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_bow_descend, dim3((n + 255) / 256), dim3(256), 0, st, desc, n, child_start, child_count,
-                       reinterpret_cast<const ulonglong4 *>(child_desc), child_id, nid_level, out);
+                       reinterpret_cast<const ulonglong4 *>(child_desc), child_id, word_id, weight, nid_level, out);
 }
 
 }  // namespace mcorb
