@@ -95,6 +95,22 @@ def test_rigs_wider_than_the_reference_track_type(mc, C):
     rig.close()
 
 
+def test_baseline_config2_eight_cameras_1080p(mc):
+    """BASELINE configs[2] on one GPU: 8-camera rig, 1920x1080, 2000 keypoints per camera, all 28 camera pairs."""
+    C, W, H, N = 8, 1920, 1080, 2000
+    imgs = [mc.synth_rig_frame(11, C, c, W, H) for c in range(C)]
+    rig = mc.Rig(C, W, H, 1, 1, nfeatures=N)
+    rig.upload(imgs)
+    rig.process(1)
+    ora = [O.OracleExtractor(N)(im) for im in imgs]
+    for c in range(C):
+        same(ora[c], rig.features(c), "cam %d" % c)
+    tr, mg = rig.tracks(0)
+    otr, omg = O.intra_matches([o[2] for o in ora])
+    assert np.array_equal(tr, otr) and mg == omg and len(tr) > 2000
+    rig.close()
+
+
 def test_matcher_thresholds(mc):
     W, H, C, N = 640, 480, 2, 800
     imgs = [mc.synth_rig_frame(9, C, c, W, H) for c in range(C)]
