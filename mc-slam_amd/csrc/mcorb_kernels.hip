@@ -581,9 +581,11 @@ __device__ __forceinline__ uint32_t load4_reflect(const uint8_t *plane, int pitc
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom g)
 {
     constexpr int TW = kBlurTW, TH = kBlurTH;
-    constexpr int ID = TW / 4 + 2;          // input dwords per row: 4 bytes of apron on each side
+    // LDS row: [3 pad dwords][left apron dword][TW/4 dwords][right apron dword], so that the tile's own columns start
+    // at a 16-byte boundary and are filled with 16-byte loads / ds_write_b128; A0 = dword index of the left apron
+    constexpr int ID = TW / 4 + 8, A0 = 3;  // pitch 160 B, a multiple of 16
     constexpr int NP = (TH + 6) / 2;        // row pairs of the horizontal result
-    __shared__ uint32_t in32[(TH + 6) * ID];
+    __shared__ __attribute__((aligned(16))) uint32_t in32[(TH + 6) * ID];
     // horizontal result, two vertically adjacent rows per dword: hp[pair][x] = h[2*pair][x] | h[2*pair+1][x] << 16,
     // so that the vertical pass is four v_dot2_u32_u16 per output pixel
     __shared__ __attribute__((aligned(16))) uint32_t hp[NP * TW];
@@ -600,54 +602,61 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     const int x0 = tx * TW, y0 = ty * TH;
     const uint8_t *plane = pyr + (size_t)img * g.imgBytes + L.off;
 
-    constexpr int NLD = ((TH + 6) * ID + 255) / 256;
     if (x0 >= 4 && x0 + TW + 4 <= L.w && y0 >= 3 && y0 + TH + 3 <= L.h) {
-        // interior tile (the common case): no border handling, all loads issued before the first LDS store
-        const uint8_t *src = plane + (size_t)(y0 - 3) * L.pitch + (x0 - 4);
-        uint32_t v[NLD];
+        // interior tile (the common case): no border handling; per row 8 x 16 bytes (x0 is a multiple of 128 and rows are
+        // 64-byte aligned) + the two apron dwords; all loads are issued before the first LDS store
+        constexpr int QR = TW / 16;                          // 16-byte chunks per row
+        constexpr int NQ = ((TH + 6) * QR + 255) / 256;      // chunk loads per thread
+        const uint8_t *src = plane + (size_t)(y0 - 3) * L.pitch + x0;
+        uint4 v[NQ];
 #pragma unroll
-        for (int k = 0; k < NLD; k++) {
+        for (int k = 0; k < NQ; k++) {
             const int i = tid + 256 * k;
-            const int r = i / ID, d = i - r * ID;
-            v[k] = i < (TH + 6) * ID ? *reinterpret_cast<const uint32_t *>(src + (size_t)r * L.pitch + 4 * d) : 0u;
+            const int r = i / QR, q = i - r * QR;
+            v[k] = i < (TH + 6) * QR ? *reinterpret_cast<const uint4 *>(src + (size_t)r * L.pitch + 16 * q) : uint4{0, 0, 0, 0};
         }
+        uint32_t ap = 0;
+        const int ar = tid >> 1, aside = tid & 1;            // threads 0 .. 2*(TH+6)-1 fetch one apron dword each
+        if (tid < 2 * (TH + 6)) ap = *reinterpret_cast<const uint32_t *>(src + (size_t)ar * L.pitch + (aside ? TW : -4));
 #pragma unroll
-        for (int k = 0; k < NLD; k++) {
+        for (int k = 0; k < NQ; k++) {
             const int i = tid + 256 * k;
-            if (i < (TH + 6) * ID) in32[i] = v[k];
+            const int r = i / QR, q = i - r * QR;
+            if (i < (TH + 6) * QR) *reinterpret_cast<uint4 *>(in32 + r * ID + A0 + 1 + 4 * q) = v[k];
         }
+        if (tid < 2 * (TH + 6)) in32[ar * ID + A0 + (aside ? TW / 4 + 1 : 0)] = ap;
     } else {
-        for (int i = tid; i < (TH + 6) * ID; i += 256) {
-            const int r = i / ID, d = i - r * ID;
+        for (int i = tid; i < (TH + 6) * (TW / 4 + 2); i += 256) {
+            const int r = i / (TW / 4 + 2), d = i - r * (TW / 4 + 2);
             int sy = reflect101(y0 + r - 3, L.h);
             sy = sy < 0 ? 0 : (sy >= L.h ? L.h - 1 : sy);
-            in32[i] = load4_reflect(plane, L.pitch, L.w, sy, x0 - 4 + 4 * d);
+            in32[r * ID + A0 + d] = load4_reflect(plane, L.pitch, L.w, sy, x0 - 4 + 4 * d);
         }
     }
     __syncthreads();
     // horizontal: work item = (row pair, group of 4 output pixels); bytes b0..b11 = tile columns 4g .. 4g+11,
-    // output pixel j sits at tile column 4g+4+j and needs b[j+1 .. j+7]; packed u16 arithmetic is exact (<= 65280)
+    // output pixel j sits at tile column 4g+4+j and needs b[j+1 .. j+7]: two v_dot4_u32_u8 on the byte windows
+    // b[j+1..j+4] (taps 18,34,48,56) and b[j+5..j+8] (taps 48,34,18,0), the second accumulating into the first;
+    // the sum is <= 65280, so it is exactly the 8.8 fixed-point value OpenCV's horizontal pass produces
     for (int i = tid; i < NP * (TW / 4); i += 256) {
         const int p = i / (TW / 4), gx = i - p * (TW / 4);
-        uint32_t o01[2], o23[2];
+        uint32_t h[2][4];
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
-            const uint32_t *row = in32 + (2 * p + rr) * ID + gx;
+            const uint32_t *row = in32 + (2 * p + rr) * ID + A0 + gx;
             const uint32_t d0 = row[0], d1 = row[1], d2 = row[2];
-#define PK(hi, lo, sel) __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(hi, lo, sel))
-            const u16x2 P1 = PK(d1, d0, 0x0c020c01u), P2 = PK(d1, d0, 0x0c030c02u), P3 = PK(d1, d0, 0x0c040c03u);
-            const u16x2 P4 = PK(d1, d0, 0x0c050c04u), P5 = PK(d1, d0, 0x0c060c05u), P6 = PK(d1, d0, 0x0c070c06u);
-            const u16x2 P7 = PK(d2, d1, 0x0c040c03u), P8 = PK(d2, d1, 0x0c050c04u), P9 = PK(d2, d1, 0x0c060c05u);
-#undef PK
-            const u16x2 k18 = {18, 18}, k34 = {34, 34}, k48 = {48, 48}, k56 = {56, 56};
-            o01[rr] = __builtin_bit_cast(uint32_t, (u16x2)(k18 * (P1 + P7) + k34 * (P2 + P6) + k48 * (P3 + P5) + k56 * P4));
-            o23[rr] = __builtin_bit_cast(uint32_t, (u16x2)(k18 * (P3 + P9) + k34 * (P4 + P8) + k48 * (P5 + P7) + k56 * P6));
+            constexpr uint32_t T1 = 0x38302212u, T2 = 0x00122230u;
+#define WIN(hi, lo, sh) ((sh) == 4 ? (hi) : __builtin_amdgcn_alignbyte(hi, lo, sh))
+#define HTAP(j) __builtin_amdgcn_udot4(WIN(d2, d1, (j) + 1), T2, __builtin_amdgcn_udot4(WIN(d1, d0, (j) + 1), T1, 0u, false), false)
+            h[rr][0] = HTAP(0); h[rr][1] = HTAP(1); h[rr][2] = HTAP(2); h[rr][3] = HTAP(3);
+#undef HTAP
+#undef WIN
         }
-        uint4 v;
-        v.x = __builtin_amdgcn_perm(o01[1], o01[0], 0x05040100u);   // (h[r][x0],   h[r+1][x0])
-        v.y = __builtin_amdgcn_perm(o01[1], o01[0], 0x07060302u);   // x0 + 1
-        v.z = __builtin_amdgcn_perm(o23[1], o23[0], 0x05040100u);   // x0 + 2
-        v.w = __builtin_amdgcn_perm(o23[1], o23[0], 0x07060302u);   // x0 + 3
+        uint4 v;   // (h[r][x], h[r+1][x]) per dword
+        v.x = __builtin_amdgcn_perm(h[1][0], h[0][0], 0x05040100u);
+        v.y = __builtin_amdgcn_perm(h[1][1], h[0][1], 0x05040100u);
+        v.z = __builtin_amdgcn_perm(h[1][2], h[0][2], 0x05040100u);
+        v.w = __builtin_amdgcn_perm(h[1][3], h[0][3], 0x05040100u);
         *reinterpret_cast<uint4 *>(hp + p * TW + 4 * gx) = v;
     }
     __syncthreads();
