@@ -327,7 +327,11 @@ int mcorb_rig_get_candidates(mcorb_rig *r, int slot, int m, int level, uint32_t 
     if (n) {
         // the device hands candidates over bucketed by quad-tree path; restore vToDistributeKeys order
         // (cell row, cell col, y, x) for the caller
-        const uint32_t *src = s->h_cand + (size_t)m * g.candCap + lo[level];
+        // (read from the device copy: the list is shipped to host memory only when the selection can need it)
+        std::vector<uint32_t> tmp(n);
+        HIPCHK(hipSetDevice(r->rig.device));
+        HIPCHK(hipMemcpy(tmp.data(), s->d_sorted + (size_t)m * g.candCap + lo[level], (size_t)n * 4, hipMemcpyDeviceToHost));
+        const uint32_t *src = tmp.data();
         const int wc = g.lv[level].wCell, hc = g.lv[level].hCell;
         std::vector<std::pair<uint64_t, uint32_t>> v(n);
         for (int i = 0; i < n; i++) {
@@ -636,10 +640,14 @@ int mcorb_host_select(const uint32_t *packed, int n, int minX, int maxX, int min
     std::vector<mcorb::BucketBest> bbest;
     host_bucket_sort(packed, n, P, sorted, perm, bstart, bbest);   // what k_compact does on the device
     std::vector<int> out((size_t)std::max(nfeatures_level, 0) + 64 + 8);
-    const int r = select_octree(sorted.data(), bstart.data(), bbest.data(), n, P, out.data(), sc);
+    std::vector<uint32_t> outv(out.size());
+    const int r = select_octree(sorted.data(), bstart.data(), bbest.data(), n, P, out.data(), outv.data(), sc);
     if (r < 0) { set_error("host_select: level too tall"); return MCORB_E_SIZE; }
     if (r > cap) { set_error("host_select: output too small"); return MCORB_E_CAP; }
-    for (int i = 0; i < r; i++) out_idx[i] = perm[out[i]];
+    for (int i = 0; i < r; i++) {
+        out_idx[i] = perm[out[i]];
+        if (outv[i] != packed[out_idx[i]]) { set_error("host_select: value/index mismatch"); return MCORB_E_STATE; }
+    }
     return r;
 }
 

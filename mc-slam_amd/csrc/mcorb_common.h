@@ -23,8 +23,9 @@ __host__ __device__ inline int cand_resp(uint32_t p) { return (int)(p & 0xffu); 
 // Winner of the reference's final pick inside one path-code bucket (ORBextractor.cpp:757-775):
 // key = response << 23 | (kPickOrderMask - position in vToDistributeKeys order), larger key wins;
 // pos = index of that candidate in the level's bucket-sorted list.  key == 0: empty bucket.
+// val = that candidate itself (packed y | x | response), so the host can build the keypoint without the list.
 constexpr int kPickOrderMask = (1 << 23) - 1;
-struct BucketBest { uint32_t key, pos; };
+struct BucketBest { uint32_t key, pos, val; };
 
 // result of the vocabulary descent of one descriptor: word id and weight of the leaf it reached (word < 0 never
 // happens for a well-formed tree), and the node id `levelsup` levels above the leaves (FeatureVector key)
@@ -50,6 +51,8 @@ struct LevelGeom {
     int depth;           // path-code depth D: buckets = nIni * 4^D
     int nBuckets;
     int bucket0;         // index of this level's first bucket-start entry inside one image (nBuckets+1 entries)
+    int quota;           // mnFeaturesPerLevel[level] (DistributeOctTree's N): candidates are shipped to the host only when
+                         // fewer than `quota` buckets are non-empty, i.e. when the tree can go deeper than the bucketing
 };
 
 struct Geom {

@@ -155,6 +155,7 @@ int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g
         L.depth = sp.depth;
         L.nBuckets = sp.nIni << (2 * sp.depth);
         L.bucket0 = buckets;
+        L.quota = t.quota[l];
         buckets += L.nBuckets + 1;
         if (L.w > 4096 || L.h > 4096) { set_error("image larger than 4096 px"); return MCORB_E_SIZE; }
         L.pitch = (int)align_up((size_t)L.w, 64);
@@ -421,6 +422,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         TRY(dev_alloc(&s->d_part, (size_t)npairs_max * nchunks * geom.kcap));
         TRY(host_alloc(&s->h_cand, M * geom.candCap));
         TRY(host_alloc(&s->h_lvloff, M * (kMaxLevels + 1)));
+        TRY(host_alloc(&s->h_shipped, M * kMaxLevels));
         TRY(host_alloc(&s->h_overflow, 16));
         TRY(host_alloc(&s->h_knn, (size_t)npairs_max * geom.kcap));
         {
@@ -442,7 +444,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         TRY(host_alloc(&s->h_angles, M * geom.kcap));
         s->kps.resize(M);
         s->mono.assign(M, 0);
-        s->sel_idx.resize(M * geom.nlevels);
+        s->sel_val.resize(M * geom.nlevels);
         s->m_idx1.resize(npairs_max);
         s->m_idx2.resize(npairs_max);
         s->tracks.resize(max_frames);
@@ -470,7 +472,7 @@ Rig::~Rig()
         if (s->st_dma) (void)hipStreamSynchronize(s->st_dma);
         (void)hipFree(s->d_pyr); (void)hipFree(s->d_blur); (void)hipFree(s->d_desc); (void)hipFree(s->d_cellkp);
         (void)hipFree(s->d_cellcnt); (void)hipFree(s->d_sorted); (void)hipHostFree(s->h_bstart); (void)hipHostFree(s->h_bbest); (void)hipFree(s->d_angles); (void)hipFree(s->d_part); (void)hipFree(s->d_f32);
-        (void)hipHostFree(s->h_cand); (void)hipHostFree(s->h_lvloff); (void)hipHostFree(s->h_overflow);
+        (void)hipHostFree(s->h_cand); (void)hipHostFree(s->h_lvloff); (void)hipHostFree(s->h_shipped); (void)hipHostFree(s->h_overflow);
         (void)hipHostFree(s->h_knn); (void)hipHostFree(s->h_ctrl); (void)hipFree(s->d_ctrl);
         (void)hipHostFree(s->h_stage);
         (void)hipHostFree(s->h_desc); (void)hipHostFree(s->h_angles);
@@ -668,7 +670,7 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
     // compaction writes the candidates over PCIe into host-mapped memory: run it on the side stream so
     // the blur (which does not depend on it) overlaps the transfer
     HIPCHK(hipStreamWaitEvent(s.st_copy, s.ev[2], 0));
-    launch_compact(s.st_copy, s.d_cellkp, s.d_cellcnt, geom, s.d_sorted, s.h_cand, s.h_lvloff, s.h_bstart, s.h_bbest, s.h_overflow,
+    launch_compact(s.st_copy, s.d_cellkp, s.d_cellcnt, geom, s.d_sorted, s.h_cand, s.h_lvloff, s.h_bstart, s.h_bbest, s.h_shipped, s.h_overflow,
                    j.nimg);
     HIPCHK(hipEventRecord(s.ev[3], s.st_copy));
     launch_blur(s.st, s.d_pyr, s.d_blur, geom, j.nimg);
@@ -699,25 +701,31 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
             // (demand loads, one per line: software prefetches were measured slower, most get dropped)
             uint32_t touch = 0;
             const uint32_t *c = s.h_cand + (size_t)m * geom.candCap;
-            for (int i = 0, e = lo[L]; i < e; i += 16) touch += c[i];
+            const int *shp = s.h_shipped + (size_t)m * kMaxLevels;
+            for (int l = 0; l < L; l++)
+                if (shp[l])
+                    for (int i = lo[l], e = lo[l + 1]; i < e; i += 16) touch += c[i];
             const uint32_t *b1 = reinterpret_cast<const uint32_t *>(s.h_bstart + (size_t)m * geom.bucketTotal);
             const uint32_t *b2 = reinterpret_cast<const uint32_t *>(s.h_bbest + (size_t)m * geom.bucketTotal);
             for (int i = 0; i < geom.bucketTotal; i += 16) touch += b1[i];
-            for (int i = 0; i < 2 * geom.bucketTotal; i += 16) touch += b2[i];
+            for (int i = 0; i < 3 * geom.bucketTotal; i += 16) touch += b2[i];
             s.touch_sink[m & 15] = touch;   // keeps the loads alive
         }
         int total = 0;
         HostProf::Scope *prof_sel = new (alloca(sizeof(HostProf::Scope))) HostProf::Scope(1);
         for (int level = 0; level < L; level++) {
             const int n = lo[level + 1] - lo[level];
-            std::vector<int> &out = s.sel_idx[(size_t)m * L + level];
+            std::vector<uint32_t> &out = s.sel_val[(size_t)m * L + level];
             out.resize((size_t)tab.quota[level] + 64);
+            std::vector<int> &idx = scratch[w]->idx;
+            idx.resize(out.size());
             int r = 0;
             if (n > 0)
-                r = select_octree(s.h_cand + (size_t)m * geom.candCap + lo[level],
+                r = select_octree(s.h_shipped[(size_t)m * kMaxLevels + level] ? s.h_cand + (size_t)m * geom.candCap + lo[level] : nullptr,
                                   s.h_bstart + (size_t)m * geom.bucketTotal + geom.lv[level].bucket0,
                                   s.h_bbest + (size_t)m * geom.bucketTotal + geom.lv[level].bucket0, n, selp[level],
-                                  out.data(), *scratch[w]);
+                                  idx.data(), out.data(), *scratch[w]);
+            if (r == -3) { bad.store(3); r = 0; }
             if (r < 0) { bad.store(1); r = 0; }
             out.resize(r);
             total += r;
@@ -731,10 +739,8 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
         int monoIndex = 0, stereoIndex = total - 1;
         if (total) {
             for (int l = 0; l < L; l++) {
-                const uint32_t *cand = s.h_cand + (size_t)m * geom.candCap + lo[l];
                 const float scale = tab.scale[l];
-                for (int idx : s.sel_idx[(size_t)m * L + l]) {
-                    const uint32_t c = cand[idx];
+                for (const uint32_t c : s.sel_val[(size_t)m * L + l]) {
                     const int xl = cand_x(c) + kMinBorder, yl = cand_y(c) + kMinBorder;
                     mcorb_keypoint kp;
                     kp.x = (float)xl; kp.y = (float)yl;
@@ -755,6 +761,7 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
         s.mono[m] = monoIndex;
         s.h_nsel[m] = total;
     }, pool_threads + s.index);
+    if (bad.load() == 3) { set_error("internal: quad-tree went below the bucketing without the candidate list"); (void)hipStreamSynchronize(s.st); return MCORB_E_STATE; }
     if (bad.load() == 1) { set_error("selection failed: level too tall"); (void)hipStreamSynchronize(s.st); return MCORB_E_SIZE; }
     if (bad.load()) { set_error("keypoint capacity exceeded"); (void)hipStreamSynchronize(s.st); return MCORB_E_CAP; }
     const auto t1 = std::chrono::steady_clock::now();

@@ -95,6 +95,7 @@ struct Slot {
     // host, device-mapped (kernels write/read these directly over PCIe)
     uint32_t *h_cand = nullptr;
     int *h_lvloff = nullptr, *h_overflow = nullptr, *h_bstart = nullptr;
+    int *h_shipped = nullptr;        // per (image, level): 1 if k_compact copied the level's candidate list to h_cand
     volatile uint32_t touch_sink[16] = {};
     BucketBest *h_bbest = nullptr;   // per bucket: winner of the final pick (k_compact)
     KnnRow *h_knn = nullptr;
@@ -114,7 +115,7 @@ struct Slot {
     // results
     std::vector<std::vector<mcorb_keypoint>> kps;   // per image
     std::vector<int> mono;
-    std::vector<std::vector<int>> sel_idx;          // per (image, level): retained candidate indices
+    std::vector<std::vector<uint32_t>> sel_val;     // per (image, level): retained candidates (packed), result order
     int npairs_done = 0, nframes_done = 0, nimg_done = 0;
     std::vector<std::vector<uint32_t>> m_idx1, m_idx2;   // per pair
     std::vector<std::vector<int32_t>> tracks;            // per frame, ncams ints per track

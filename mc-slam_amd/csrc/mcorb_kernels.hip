@@ -452,15 +452,16 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int *wsum, int *
 __global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ cell_kp, const int *__restrict__ cell_cnt,
                                                   Geom g, uint32_t *__restrict__ sorted_dev, uint32_t *__restrict__ cand,
                                                   int *__restrict__ lvl_off, int *__restrict__ bstart, BucketBest *__restrict__ bbest,
-                                                  int *__restrict__ overflow, int exclCap, int bktCap)
+                                                  int *__restrict__ shipped, int *__restrict__ overflow, int exclCap, int bktCap)
 {
-    extern __shared__ int sh[];     // excl[exclCap] | hist[bktCap] | bkey[bktCap] | bpos[bktCap]
+    extern __shared__ int sh[];     // excl[exclCap] | hist[bktCap] | bkey[bktCap] | bpos[bktCap] | bval[bktCap]
     int *excl = sh;                 // exclusive offsets of this level's cells (+1 entry for the total)
     int *hist = sh + exclCap;
     uint32_t *bkey = reinterpret_cast<uint32_t *>(hist + bktCap);
     int *bpos = hist + 2 * bktCap;
+    uint32_t *hist_val = reinterpret_cast<uint32_t *>(hist + 3 * bktCap);   // the winner's packed candidate
     __shared__ int wsum[16];
-    __shared__ int s_tot, s_base;
+    __shared__ int s_tot, s_base, s_nz;
     const int tid = threadIdx.x;
     const int level = blockIdx.x, img = blockIdx.y;
     const LevelGeom &L = g.lv[level];
@@ -474,7 +475,8 @@ __global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ c
     for (int c = tid; c < L.cell0; c += 1024) { const int v = cnt[c]; s += v < cap ? v : cap; }
     (void)block_exclusive_scan_1024(s, wsum, &s_base);
     const int base = s_base;
-    for (int b = tid; b <= B; b += 1024) { hist[b] = 0; bkey[b] = 0; bpos[b] = 0; }
+    for (int b = tid; b <= B; b += 1024) { hist[b] = 0; bkey[b] = 0; bpos[b] = 0; hist_val[b] = 0; }
+    if (tid == 0) s_nz = 0;
     __syncthreads();
 
     // exclusive scan over this level's cells: each thread owns a contiguous run of cells
@@ -520,8 +522,9 @@ __global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ c
     {
         const int bper = (B + 1023) >> 10;
         const int b0 = tid * bper;
-        int bs = 0;
-        for (int k = 0; k < bper; k++) if (b0 + k < B) bs += hist[b0 + k];
+        int bs = 0, nzl = 0;
+        for (int k = 0; k < bper; k++) if (b0 + k < B) { bs += hist[b0 + k]; nzl += hist[b0 + k] > 0; }
+        if (nzl) atomicAdd(&s_nz, nzl);
         int brun = block_exclusive_scan_1024(bs, wsum, &s_tot);
         for (int k = 0; k < bper; k++) {
             if (b0 + k < B) { const int v = hist[b0 + k]; hist[b0 + k] = brun; brun += v; }
@@ -544,14 +547,23 @@ __global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ c
         const uint32_t code = path_code(cand_x(p), cand_y(p), W0, H0, L.nIni, L.hX, L.depth);
         const int slot = atomicAdd(&hist[code], 1);
         sd[slot] = p;
-        if (bkey[code] == (((uint32_t)cand_resp(p) << 23) | (uint32_t)(kPickOrderMask - i))) bpos[code] = slot;   // keys are unique
+        if (bkey[code] == (((uint32_t)cand_resp(p) << 23) | (uint32_t)(kPickOrderMask - i))) {   // keys are unique
+            bpos[code] = slot;
+            hist_val[code] = p;
+        }
     }
     __syncthreads();   // the workgroup's own global stores are visible to it after the barrier
     BucketBest *bb_out = bbest + (size_t)img * g.bucketTotal + L.bucket0;
-    for (int b = tid; b < B; b += 1024) bb_out[b] = BucketBest{bkey[b], (uint32_t)bpos[b]};
-    // coalesced copy-out over PCIe into host-mapped memory
-    uint32_t *dst = cand + (size_t)img * g.candCap + base;
-    for (int i = tid; i < T; i += 1024) dst[i] = sd[i];
+    for (int b = tid; b < B; b += 1024) bb_out[b] = BucketBest{bkey[b], (uint32_t)bpos[b], hist_val[b]};
+    // The list itself goes over PCIe only when the host can need it: DistributeOctTree divides a depth-D node (one
+    // bucket) only after every node reached depth D with fewer than N nodes in total, and at that point the node count
+    // equals the number of non-empty buckets.  With nz >= N the host works from bstart/bbest alone.
+    const bool ship = s_nz < L.quota;
+    if (tid == 0) shipped[(size_t)img * kMaxLevels + level] = ship ? 1 : 0;
+    if (ship) {
+        uint32_t *dst = cand + (size_t)img * g.candCap + base;
+        for (int i = tid; i < T; i += 1024) dst[i] = sd[i];   // coalesced copy-out into host-mapped memory
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1088,7 +1100,7 @@ void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, i
 }
 
 void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt, const Geom &g, uint32_t *sorted_dev,
-                    uint32_t *cand, int *lvl_off, int *bstart, BucketBest *bbest, int *overflow, int nimg)
+                    uint32_t *cand, int *lvl_off, int *bstart, BucketBest *bbest, int *shipped, int *overflow, int nimg)
 {
     int maxc = 1, maxb = 1;
     for (int l = 0; l < g.nlevels; l++) {
@@ -1097,8 +1109,8 @@ void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt
     }
     const int exclCap = (maxc + 1 + 3) & ~3;
     const int bktCap = (maxb + 1 + 3) & ~3;
-    hipLaunchKernelGGL(k_compact, dim3(g.nlevels, nimg), dim3(1024), (size_t)(exclCap + 3 * bktCap) * sizeof(int), st, cell_kp,
-                       cell_cnt, g, sorted_dev, cand, lvl_off, bstart, bbest, overflow, exclCap, bktCap);
+    hipLaunchKernelGGL(k_compact, dim3(g.nlevels, nimg), dim3(1024), (size_t)(exclCap + 4 * bktCap) * sizeof(int), st, cell_kp,
+                       cell_cnt, g, sorted_dev, cand, lvl_off, bstart, bbest, shipped, overflow, exclCap, bktCap);
 }
 
 void launch_blur(hipStream_t st, const uint8_t *pyr, uint8_t *blur, const Geom &g, int nimg)

@@ -68,7 +68,7 @@ SelectScratch::SelectScratch() : impl(new Impl) {}
 SelectScratch::~SelectScratch() { delete impl; }
 
 // DivideNode (:479-535): children in n1..n4 order; child[q] = -1 where a child has no keys.
-static void divide(SelectScratch::Impl &S, const uint32_t *cand, const int *bstart, int D, int id, int child[4])
+static bool divide(SelectScratch::Impl &S, const uint32_t *cand, const int *bstart, int D, int id, int child[4])
 {
     const Node P = S.nodes[id];
     const int sx = P.x0 + ((P.x1 - P.x0 + 1) >> 1);   // UL.x + ceil((UR.x-UL.x)/2)
@@ -84,6 +84,7 @@ static void divide(SelectScratch::Impl &S, const uint32_t *cand, const int *bsta
             cnt[q] = bstart[(c + 1) << shift] - beg[q];
         }
     } else {
+        if (!cand) return false;   // the candidate list was not shipped: cannot happen when nz >= N (see k_compact)
         in_arena = true;
         cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
         if ((int)S.quad.size() < P.cnt) S.quad.resize(P.cnt);
@@ -115,10 +116,11 @@ static void divide(SelectScratch::Impl &S, const uint32_t *cand, const int *bsta
         n.noMore = (cnt[q] == 1);
         child[q] = c;
     }
+    return true;
 }
 
 int select_octree(const uint32_t *cand, const int *bstart, const BucketBest *bbest, int n, const SelectParams &P, int *out_idx,
-                  SelectScratch &scratch)
+                  uint32_t *out_val, SelectScratch &scratch)
 {
     SelectScratch::Impl &S = *scratch.impl;
     S.nodes.clear(); S.arena.clear(); S.expand.clear(); S.prevExpand.clear();
@@ -160,7 +162,7 @@ int select_octree(const uint32_t *cand, const int *bstart, const BucketBest *bbe
         for (int it = S.head; it >= 0;) {
             if (S.nodes[it].noMore) { it = S.nodes[it].next; continue; }
             int ch[4];
-            divide(S, cand, bstart, D, it, ch);
+            if (!divide(S, cand, bstart, D, it, ch)) return -3;
             for (int q = 0; q < 4; q++) {
                 if (ch[q] < 0) continue;
                 S.push_front(ch[q]);
@@ -189,7 +191,7 @@ int select_octree(const uint32_t *cand, const int *bstart, const BucketBest *bbe
                 for (int j = (int)S.prevExpand.size() - 1; j >= 0; j--) {
                     const int id = S.prevExpand[j].second;
                     int ch[4];
-                    divide(S, cand, bstart, D, id, ch);
+                    if (!divide(S, cand, bstart, D, id, ch)) return -3;
                     for (int q = 0; q < 4; q++) {
                         if (ch[q] < 0) continue;
                         S.push_front(ch[q]);
@@ -208,18 +210,20 @@ int select_octree(const uint32_t *cand, const int *bstart, const BucketBest *bbe
     int m = 0;
     for (int it = S.head; it >= 0; it = S.nodes[it].next) {
         const Node &nd = S.nodes[it];
-        if (nd.cnt == 1) { out_idx[m++] = nd.arena ? S.arena[nd.beg] : nd.beg; continue; }
         if (!nd.arena) {
             // the node is a run of buckets whose winners the GPU already found: the largest key wins
+            // (a single-key node is the one non-empty bucket of its run)
             const int shift = 2 * (D - nd.d);
             const BucketBest *bb = bbest + ((size_t)nd.code << shift);
             const int nb = 1 << shift;
-            uint32_t bestKey = 0, bestPos = 0;
+            uint32_t bestKey = 0, bestPos = 0, bestVal = 0;
             for (int b = 0; b < nb; b++)
-                if (bb[b].key > bestKey) { bestKey = bb[b].key; bestPos = bb[b].pos; }
+                if (bb[b].key > bestKey) { bestKey = bb[b].key; bestPos = bb[b].pos; bestVal = bb[b].val; }
+            out_val[m] = bestVal;
             out_idx[m++] = (int)bestPos;
             continue;
         }
+        if (nd.cnt == 1) { out_val[m] = cand[S.arena[nd.beg]]; out_idx[m++] = S.arena[nd.beg]; continue; }
         int best = -1, bestR = -1;
         uint64_t bestO = 0;
         for (int k = 0; k < nd.cnt; k++) {
@@ -232,6 +236,7 @@ int select_octree(const uint32_t *cand, const int *bstart, const BucketBest *bbe
                                (uint64_t)x;
             if (r > bestR || o < bestO) { bestR = r; best = idx; bestO = o; }
         }
+        out_val[m] = cand[best];
         out_idx[m++] = best;
     }
     return m;
@@ -254,13 +259,13 @@ void host_bucket_sort(const uint32_t *cand, int n, const SelectParams &P, std::v
     std::vector<int> pos(bstart.begin(), bstart.end() - 1);
     sorted.resize(n);
     perm.resize(n);
-    bbest.assign((size_t)B, BucketBest{0, 0});
+    bbest.assign((size_t)B, BucketBest{0, 0, 0});
     for (int i = 0; i < n; i++) {
         const int s = pos[code[i]]++;
         sorted[s] = cand[i];
         perm[s] = i;
         const uint32_t key = ((uint32_t)cand_resp(cand[i]) << 23) | (uint32_t)(kPickOrderMask - i);
-        if (key > bbest[code[i]].key) bbest[code[i]] = BucketBest{key, (uint32_t)s};
+        if (key > bbest[code[i]].key) bbest[code[i]] = BucketBest{key, (uint32_t)s, cand[i]};
     }
 }
 

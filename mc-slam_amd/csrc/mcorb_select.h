@@ -10,6 +10,7 @@ namespace mcorb {
 struct SelectScratch {
     struct Impl;
     Impl *impl;
+    std::vector<int> idx;   // caller's index buffer (select_octree's out_idx)
     SelectScratch();
     ~SelectScratch();
     SelectScratch(const SelectScratch &) = delete;
@@ -31,8 +32,10 @@ SelectParams make_select_params(int minX, int maxX, int minY, int maxY, int N, i
 // nIni*4^depth + 1 bucket start offsets.  out_idx: indices INTO cand of the retained candidates
 // in the reference's result order; needs room for N + 64 entries.  Returns the count, or -2 if
 // the level is too tall for a root node (the reference divides by zero there).
+// out_val: the retained candidates themselves (packed).  cand may be null when the level's list was not shipped
+// (k_compact ships it only if fewer than N buckets are non-empty); -3 if the tree then wanted to go deeper.
 int select_octree(const uint32_t *cand, const int *bstart, const BucketBest *bbest, int n, const SelectParams &P, int *out_idx,
-                  SelectScratch &scratch);
+                  uint32_t *out_val, SelectScratch &scratch);
 
 // host statement of k_compact's counting sort for one level (test hook only)
 void host_bucket_sort(const uint32_t *cand, int n, const SelectParams &P, std::vector<uint32_t> &sorted,

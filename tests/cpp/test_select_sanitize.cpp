@@ -35,6 +35,7 @@ static int run_case(std::mt19937 &rng, int W, int H, int N, int npts, int box)
     }
     const int n = (int)packed.size();
     std::vector<int> want(n + 8), got(N + 64 + 8);
+    std::vector<uint32_t> gotv(N + 64 + 8);
     const int nw = orc_distribute_octree(fx.data(), fy.data(), fr.data(), n, 16, W - 16, 16, H - 16, N, want.data(), (int)want.size());
     const mcorb::SelectParams P = mcorb::make_select_params(16, W - 16, 16, H - 16, N, 0, 0);
     std::vector<uint32_t> sorted;
@@ -42,10 +43,10 @@ static int run_case(std::mt19937 &rng, int W, int H, int N, int npts, int box)
     std::vector<mcorb::BucketBest> bbest;
     mcorb::host_bucket_sort(packed.data(), n, P, sorted, perm, bstart, bbest);
     static mcorb::SelectScratch sc;
-    const int ng = mcorb::select_octree(sorted.data(), bstart.data(), bbest.data(), n, P, got.data(), sc);
+    const int ng = mcorb::select_octree(sorted.data(), bstart.data(), bbest.data(), n, P, got.data(), gotv.data(), sc);
     if (ng != nw) { fprintf(stderr, "count %d != %d (W %d H %d N %d n %d box %d)\n", ng, nw, W, H, N, n, box); return 1; }
     for (int i = 0; i < ng; i++)
-        if (perm[got[i]] != want[i]) { fprintf(stderr, "entry %d differs (W %d H %d N %d n %d box %d)\n", i, W, H, N, n, box); return 1; }
+        if (perm[got[i]] != want[i] || gotv[i] != packed[want[i]]) { fprintf(stderr, "entry %d differs (W %d H %d N %d n %d box %d)\n", i, W, H, N, n, box); return 1; }
     return 0;
 }
 
