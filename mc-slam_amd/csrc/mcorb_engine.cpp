@@ -445,12 +445,17 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         s->kps.resize(M);
         s->mono.assign(M, 0);
         s->sel_val.resize(M * geom.nlevels);
+        s->sel_pending = std::unique_ptr<std::atomic<int>[]>(new std::atomic<int>[M]);
         s->m_idx1.resize(npairs_max);
         s->m_idx2.resize(npairs_max);
         s->tracks.resize(max_frames);
         s->mergeable.assign(max_frames, 0);
         s->th = std::thread([this, s] { driver(s); });
     }
+    // The hipMemset calls above run on the null stream and return before the fill kernels have executed; the slots'
+    // streams are non-blocking, i.e. NOT ordered against the null stream, so without this an early upload could be
+    // zeroed again by a fill that was still queued (seen as an occasional empty first frame).
+    HIPCHK(hipDeviceSynchronize());
     return MCORB_OK;
 }
 
@@ -690,30 +695,46 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     const auto t0 = std::chrono::steady_clock::now();
     const int L = geom.nlevels, nimg = j.nimg;
     std::atomic<int> bad{0};
-    // selection + assembly: one task per image (all its levels); the host side of a level is now
-    // ~10 us of tree logic on GPU-bucketed candidates, so finer tasks would only pay pool overhead
-    pool->parallel_for(nimg, [&](int m, int w) {
+    // selection + assembly: one task per image.  The task body can split an image's levels into `parts` quota-balanced
+    // groups (whichever task finishes an image last assembles it), but with a single rig frame per call the extra tasks
+    // only wait for sleeping workers to wake up: measured 0.64-0.70 ms per frame with two parts against 0.55-0.60 with one.
+    const int parts = 1;
+    int part_of[kMaxLevels];
+    {
+        int load[2] = {0, 0};
+        for (int l = 0; l < L; l++) {   // levels come in descending quota: greedy assignment balances the two groups
+            const int p = parts == 2 && load[1] < load[0] ? 1 : 0;
+            part_of[l] = p;
+            load[p] += tab.quota[l];
+        }
+    }
+    for (int m = 0; m < nimg; m++) s.sel_pending[m].store(parts, std::memory_order_relaxed);
+    pool->parallel_for(nimg * parts, [&](int task, int w) {
         HostProf::Scope prof_task(0);
+        const int m = task / parts, part = task - m * parts;
         const int *lo = s.h_lvloff + (size_t)m * (kMaxLevels + 1);
+        const int *shp = s.h_shipped + (size_t)m * kMaxLevels;
         {
-            // the GPU wrote these over PCIe, so they sit in DRAM, not in this core's caches: stream-prefetch them
-            // (candidates ~130 KB, bucket tables ~30 KB per image) instead of taking the misses one by one below
-            // (demand loads, one per line: software prefetches were measured slower, most get dropped)
+            // the GPU wrote these over PCIe, so they sit in DRAM, not in this core's caches: stream them in with one
+            // demand load per cache line instead of taking the misses one by one below (software prefetches were
+            // measured slower, most get dropped)
             uint32_t touch = 0;
             const uint32_t *c = s.h_cand + (size_t)m * geom.candCap;
-            const int *shp = s.h_shipped + (size_t)m * kMaxLevels;
-            for (int l = 0; l < L; l++)
-                if (shp[l])
-                    for (int i = lo[l], e = lo[l + 1]; i < e; i += 16) touch += c[i];
             const uint32_t *b1 = reinterpret_cast<const uint32_t *>(s.h_bstart + (size_t)m * geom.bucketTotal);
             const uint32_t *b2 = reinterpret_cast<const uint32_t *>(s.h_bbest + (size_t)m * geom.bucketTotal);
-            for (int i = 0; i < geom.bucketTotal; i += 16) touch += b1[i];
-            for (int i = 0; i < 3 * geom.bucketTotal; i += 16) touch += b2[i];
-            s.touch_sink[m & 15] = touch;   // keeps the loads alive
+            for (int l = 0; l < L; l++) {
+                if (part_of[l] != part) continue;
+                if (shp[l])
+                    for (int i = lo[l], e = lo[l + 1]; i < e; i += 16) touch += c[i];
+                const int b0 = geom.lv[l].bucket0, nb = geom.lv[l].nBuckets + 1;
+                for (int i = b0; i < b0 + nb; i += 16) touch += b1[i];
+                for (int i = 3 * b0; i < 3 * (b0 + nb); i += 16) touch += b2[i];
+            }
+            s.touch_sink[task & 15] = touch;   // keeps the loads alive
         }
-        int total = 0;
         HostProf::Scope *prof_sel = new (alloca(sizeof(HostProf::Scope))) HostProf::Scope(1);
         for (int level = 0; level < L; level++) {
+            if (part_of[level] != part) continue;
             const int n = lo[level + 1] - lo[level];
             std::vector<uint32_t> &out = s.sel_val[(size_t)m * L + level];
             out.resize((size_t)tab.quota[level] + 64);
@@ -721,17 +742,19 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
             idx.resize(out.size());
             int r = 0;
             if (n > 0)
-                r = select_octree(s.h_shipped[(size_t)m * kMaxLevels + level] ? s.h_cand + (size_t)m * geom.candCap + lo[level] : nullptr,
+                r = select_octree(shp[level] ? s.h_cand + (size_t)m * geom.candCap + lo[level] : nullptr,
                                   s.h_bstart + (size_t)m * geom.bucketTotal + geom.lv[level].bucket0,
                                   s.h_bbest + (size_t)m * geom.bucketTotal + geom.lv[level].bucket0, n, selp[level],
                                   idx.data(), out.data(), *scratch[w]);
             if (r == -3) { bad.store(3); r = 0; }
             if (r < 0) { bad.store(1); r = 0; }
             out.resize(r);
-            total += r;
         }
         prof_sel->~Scope();
+        if (s.sel_pending[m].fetch_sub(1, std::memory_order_acq_rel) != 1) return;   // another part of this image is still running
         // assembly (ORBextractor.cpp:1103-1170): final order, lapping partition, coordinate scaling
+        int total = 0;
+        for (int l = 0; l < L; l++) total += (int)s.sel_val[(size_t)m * L + l].size();
         if (total > geom.kcap) { bad.store(2); total = 0; }
         std::vector<mcorb_keypoint> &K = s.kps[m];
         K.assign(total, mcorb_keypoint{});
@@ -923,25 +946,26 @@ int Rig::finish_match(Slot &s, const Job &j)
     (void)j;
     HostProf::Scope prof(2);
     const int C = ncams;
-    auto one_frame = [&](int f, int) {
-        int pi = f * npp;
-        for (int a = 0; a < C - 1; a++) {
-            for (int b = a + 1; b < C; b++, pi++) {
-                std::vector<uint32_t> &i1 = s.m_idx1[pi], &i2 = s.m_idx2[pi];
-                i1.clear(); i2.clear();
-                const int nq = s.match_counts[f * C + a];
-                const KnnRow *rows = s.h_knn + (size_t)pi * geom.kcap;
-                for (int q = 0; q < nq; q++) {
-                    const KnnRow &r = rows[q];
-                    if (knn_accept(r)) { i1.push_back((uint32_t)q); i2.push_back((uint32_t)knn_idx0(r)); }
-                }
-            }
+    auto filter_pair = [&](int pi, int) {   // BruteForceMatch's accept loop for one camera pair (pair index within the job)
+        const int f = pi / npp;
+        int a = 0, rem = pi - f * npp;
+        while (rem >= C - 1 - a) { rem -= C - 1 - a; a++; }   // pair (a, b) number rem of frame f, a < b
+        std::vector<uint32_t> &i1 = s.m_idx1[pi], &i2 = s.m_idx2[pi];
+        i1.clear(); i2.clear();
+        const int nq = s.match_counts[f * C + a];
+        const KnnRow *rows = s.h_knn + (size_t)pi * geom.kcap;
+        for (int q = 0; q < nq; q++) {
+            const KnnRow &r = rows[q];
+            if (knn_accept(r)) { i1.push_back((uint32_t)q); i2.push_back((uint32_t)knn_idx0(r)); }
         }
+    };
+    auto one_frame = [&](int f, int w) {
+        for (int pi = f * npp; pi < (f + 1) * npp; pi++) filter_pair(pi, w);
         merge_tracks(s, f, nullptr, s.tracks[f], s.mergeable[f]);
     };
     // frames are independent (own pair lists, own track table): one pool task each
     if (s.nframes_done > 1) pool->parallel_for(s.nframes_done, one_frame, pool_threads + s.index);
-    else if (s.nframes_done == 1) one_frame(0, 0);
+    else if (s.nframes_done == 1) one_frame(0, 0);   // (spreading one frame's pairs over the pool was slower: wake-ups)
     if (s.npairs_done > 0) {
         float m = 0;
         (void)hipEventElapsedTime(&m, s.ev[7], s.ev[9]); s.timing[3] = m * 1000.f;
