@@ -155,6 +155,7 @@ def main():
         all_cnt = [torch.zeros(N * F * NCAMS, dtype=torch.int32, device="cuda") for _ in range(G)]
         my_frames, sets = shard.match_sets(rank, N, NCAMS, total_frames)   # gathered set index of (f, c)
         assert len(my_frames) == F
+        torch.cuda.synchronize()   # the zero fills above ran on torch's stream; the engine writes these tensors from its own
 
     def extract_submit(g):
         for i in range(SG):
