@@ -17,6 +17,8 @@ struct mcorb_extractor {
     uint8_t *d_desc = nullptr;
     uint2 *d_part = nullptr;
     KnnRow *h_rows = nullptr;
+    uint32_t *h_mlist = nullptr;
+    int *h_mcount = nullptr;
     int *h_counts = nullptr;
     int2 *h_pair = nullptr;
     int kc = 0;
@@ -431,6 +433,9 @@ static void free_knn_scratch(mcorb_t *e)
     if (e->d_desc) (void)hipFree(e->d_desc);
     if (e->d_part) (void)hipFree(e->d_part);
     if (e->h_rows) (void)hipHostFree(e->h_rows);
+    if (e->h_mlist) (void)hipHostFree(e->h_mlist);
+    if (e->h_mcount) (void)hipHostFree(e->h_mcount);
+    e->h_mlist = nullptr; e->h_mcount = nullptr;
     if (e->h_counts) (void)hipHostFree(e->h_counts);
     if (e->h_pair) (void)hipHostFree(e->h_pair);
     e->d_desc = nullptr; e->d_part = nullptr; e->h_rows = nullptr; e->h_counts = nullptr; e->h_pair = nullptr;
@@ -585,6 +590,8 @@ static int knn2_host_arrays(mcorb_t *e, const uint8_t *q, int nq, const uint8_t 
         HIPCHK(hipMalloc((void **)&e->d_desc, (size_t)2 * need * 32));
         HIPCHK(hipMalloc((void **)&e->d_part, (size_t)nchunks * need * sizeof(uint2)));
         HIPCHK(hipHostMalloc((void **)&e->h_rows, (size_t)need * sizeof(KnnRow), hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void **)&e->h_mlist, (size_t)need * sizeof(uint32_t), hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void **)&e->h_mcount, sizeof(int), hipHostMallocMapped));
         HIPCHK(hipHostMalloc((void **)&e->h_counts, 2 * sizeof(int), hipHostMallocMapped));
         HIPCHK(hipHostMalloc((void **)&e->h_pair, sizeof(int2), hipHostMallocMapped));
         e->kc = need;
@@ -594,7 +601,7 @@ static int knn2_host_arrays(mcorb_t *e, const uint8_t *q, int nq, const uint8_t 
     e->h_counts[0] = nq;
     e->h_counts[1] = nt;
     e->h_pair[0] = int2{0, 1};
-    launch_knn2(nullptr, e->d_desc, e->h_counts, e->h_pair, 1, e->kc, e->d_part, thr, ratio, e->h_rows, nullptr);
+    launch_knn2(nullptr, e->d_desc, e->h_counts, e->h_pair, 1, e->kc, e->d_part, thr, ratio, e->h_rows, e->h_mlist, e->h_mcount, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(nullptr));
     return MCORB_OK;

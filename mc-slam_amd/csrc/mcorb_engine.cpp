@@ -425,6 +425,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         TRY(host_alloc(&s->h_shipped, M * kMaxLevels));
         TRY(host_alloc(&s->h_overflow, 16));
         TRY(host_alloc(&s->h_knn, (size_t)npairs_max * geom.kcap));
+        TRY(host_alloc(&s->h_mlist, (size_t)npairs_max * geom.kcap));
+        TRY(host_alloc(&s->h_mcount, (size_t)npairs_max));
         {
             const size_t o_nsel = 4096 * sizeof(int);
             const size_t o_pairs = align_up(o_nsel + M * sizeof(int), 64);
@@ -478,7 +480,7 @@ Rig::~Rig()
         (void)hipFree(s->d_pyr); (void)hipFree(s->d_blur); (void)hipFree(s->d_desc); (void)hipFree(s->d_cellkp);
         (void)hipFree(s->d_cellcnt); (void)hipFree(s->d_sorted); (void)hipHostFree(s->h_bstart); (void)hipHostFree(s->h_bbest); (void)hipFree(s->d_angles); (void)hipFree(s->d_part); (void)hipFree(s->d_f32);
         (void)hipHostFree(s->h_cand); (void)hipHostFree(s->h_lvloff); (void)hipHostFree(s->h_shipped); (void)hipHostFree(s->h_overflow);
-        (void)hipHostFree(s->h_knn); (void)hipHostFree(s->h_ctrl); (void)hipFree(s->d_ctrl);
+        (void)hipHostFree(s->h_knn); (void)hipHostFree(s->h_mlist); (void)hipHostFree(s->h_mcount); (void)hipHostFree(s->h_ctrl); (void)hipFree(s->d_ctrl);
         (void)hipHostFree(s->h_stage);
         (void)hipHostFree(s->h_desc); (void)hipHostFree(s->h_angles);
         for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
@@ -869,7 +871,7 @@ int Rig::enqueue_match(Slot &s, const Job &j, bool ctrl_on_device)
     const bool ext = j.ext_desc != nullptr;
     HIPCHK(hipEventRecord(s.ev[7], s.st));
     launch_knn2(s.st, ext ? (const uint8_t *)j.ext_desc : s.d_desc, ext ? s.d_extcounts : s.d_nsel, s.d_pairs,
-                s.npairs_done, geom.kcap, s.d_part, j.dist_thresh, j.ratio, s.h_knn, s.ev[8]);
+                s.npairs_done, geom.kcap, s.d_part, j.dist_thresh, j.ratio, s.h_knn, s.h_mlist, s.h_mcount, s.ev[8]);
     HIPCHK(hipEventRecord(s.ev[9], s.st));
     HIPCHK(hipGetLastError());
     return MCORB_OK;
@@ -945,19 +947,14 @@ int Rig::finish_match(Slot &s, const Job &j)
 {
     (void)j;
     HostProf::Scope prof(2);
-    const int C = ncams;
+    (void)ncams;
     auto filter_pair = [&](int pi, int) {   // BruteForceMatch's accept loop for one camera pair (pair index within the job)
-        const int f = pi / npp;
-        int a = 0, rem = pi - f * npp;
-        while (rem >= C - 1 - a) { rem -= C - 1 - a; a++; }   // pair (a, b) number rem of frame f, a < b
+        // k_knn2_finalize already compacted the accepted pairs in query order: unpack query << 16 | train
         std::vector<uint32_t> &i1 = s.m_idx1[pi], &i2 = s.m_idx2[pi];
-        i1.clear(); i2.clear();
-        const int nq = s.match_counts[f * C + a];
-        const KnnRow *rows = s.h_knn + (size_t)pi * geom.kcap;
-        for (int q = 0; q < nq; q++) {
-            const KnnRow &r = rows[q];
-            if (knn_accept(r)) { i1.push_back((uint32_t)q); i2.push_back((uint32_t)knn_idx0(r)); }
-        }
+        const int n = s.h_mcount[pi];
+        const uint32_t *ml = s.h_mlist + (size_t)pi * geom.kcap;
+        i1.resize(n); i2.resize(n);
+        for (int k = 0; k < n; k++) { i1[k] = ml[k] >> 16; i2[k] = ml[k] & 0xffffu; }
     };
     auto one_frame = [&](int f, int w) {
         for (int pi = f * npp; pi < (f + 1) * npp; pi++) filter_pair(pi, w);

@@ -100,6 +100,8 @@ struct Slot {
     volatile uint32_t touch_sink[16] = {};
     BucketBest *h_bbest = nullptr;   // per bucket: winner of the final pick (k_compact)
     KnnRow *h_knn = nullptr;
+    uint32_t *h_mlist = nullptr;     // per pair: accepted (query << 16 | train), query order (k_knn2_finalize)
+    int *h_mcount = nullptr;
     // control block: one pinned host buffer + one device mirror, copied with a single
     // hipMemcpyAsync: [extcounts 4096 ints][nsel][pairs][sel]
     uint8_t *h_ctrl = nullptr, *d_ctrl = nullptr;

@@ -30,7 +30,7 @@ void launch_blur(hipStream_t st, const uint8_t *pyr, uint8_t *blur, const Geom &
 void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, const Geom &g, const uint32_t *sel,
                      const int *nsel, int orientation, uint8_t *desc, float *angles, int nimg);
 void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const int2 *pairs, int npairs, int kcap,
-                 uint2 *part, float dist_thresh, float ratio, KnnRow *out, hipEvent_t ev_mid);
+                 uint2 *part, float dist_thresh, float ratio, KnnRow *out, uint32_t *mlist, int *mcount, hipEvent_t ev_mid);
 
 void launch_bow_best2(hipStream_t st, const uint8_t *desc, const int *sets, int kcap, int ncams, const float *yv,
                       const int *slot_of, const int2 *node_range, const int *node_feats, const int *nfeat, int4 *out);

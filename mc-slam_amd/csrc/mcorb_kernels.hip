@@ -962,38 +962,58 @@ __global__ __launch_bounds__(64) void k_knn2(const uint8_t *__restrict__ desc, c
 // Merge chunk partials, emit the knnMatch table and BruteForceMatch's accept
 // flag: m0.distance < ratio * m1.distance && !(m0.distance > dist_thresh)
 // (MultiCameraFrame.cpp:1061-1063), float arithmetic as in the reference.
-__global__ __launch_bounds__(256) void k_knn2_finalize(const uint2 *__restrict__ part, const int *__restrict__ counts,
-                                                       const int2 *__restrict__ pairs, int kcap, int nchunks,
-                                                       float dist_thresh, float ratio, KnnRow *__restrict__ out)
+__global__ __launch_bounds__(1024) void k_knn2_finalize(const uint2 *__restrict__ part, const int *__restrict__ counts,
+                                                        const int2 *__restrict__ pairs, int kcap, int nchunks,
+                                                        float dist_thresh, float ratio, KnnRow *__restrict__ out,
+                                                        uint32_t *__restrict__ mlist, int *__restrict__ mcount)
 {
-    const int pair = blockIdx.y;
-    const int q = blockIdx.x * 256 + threadIdx.x;
+    // One workgroup per camera pair: besides the k-NN rows it emits BruteForceMatch's accepted (query, train) pairs
+    // compacted in query order (mlist[pair][k] = query << 16 | train, mcount[pair]), so the host does not scan the rows.
+    __shared__ int wsum[16];
+    __shared__ int s_run;
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int2 qt = pairs[pair];
     const int nq = counts[qt.x], nt = counts[qt.y];
-    if (q >= nq) return;
-    uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu;
     const int used = (nt + kKnnChunk - 1) / kKnnChunk;
-    for (int c = 0; c < used; c++) {
-        const uint2 p = part[((size_t)pair * nchunks + c) * kcap + q];
-        // insert p.x then p.y
-        uint32_t key = p.x;
-        uint32_t lo = key < k0 ? key : k0, hi = key < k0 ? k0 : key;
-        k1 = hi < k1 ? hi : k1; k0 = lo;
-        key = p.y;
-        lo = key < k0 ? key : k0; hi = key < k0 ? k0 : key;
-        k1 = hi < k1 ? hi : k1; k0 = lo;
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < nq; base += 1024) {
+        const int q = base + tid;
+        uint32_t acc = 0, t0 = 0;
+        if (q < nq) {
+            uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu;
+            for (int c = 0; c < used; c++) {
+                const uint2 p = part[((size_t)pair * nchunks + c) * kcap + q];
+                knn_insert(p.x, k0, k1);
+                knn_insert(p.y, k0, k1);
+            }
+            const bool v0 = k0 != 0xffffffffu, v1 = k1 != 0xffffffffu;
+            const uint32_t d0 = v0 ? k0 >> 16 : 0u, d1 = v1 ? k1 >> 16 : 0u;
+            if (v0 && v1) {
+                const float f0 = (float)d0, f1 = (float)d1;   // DMatch::distance is float
+                acc = (f0 < __fmul_rn(ratio, f1)) && !(f0 > dist_thresh);
+            }
+            t0 = k0 & 0xffffu;
+            KnnRow r;
+            r.idx = (v0 ? t0 : 0xffffu) | ((v1 ? (k1 & 0xffffu) : 0xffffu) << 16);
+            r.d = d0 | (d1 << 9) | (acc << 18);
+            out[(size_t)pair * kcap + q] = r;
+        }
+        const unsigned long long b = __ballot(acc != 0);
+        if (lane == 0) wsum[wave] = __popcll(b);
+        __syncthreads();
+        int before = s_run;
+        for (int w = 0; w < wave; w++) before += wsum[w];
+        if (acc) mlist[(size_t)pair * kcap + lane_rank(b, before)] = ((uint32_t)q << 16) | t0;
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += wsum[w];
+            s_run += tot;
+        }
+        __syncthreads();
     }
-    const bool v0 = k0 != 0xffffffffu, v1 = k1 != 0xffffffffu;
-    const uint32_t d0 = v0 ? k0 >> 16 : 0u, d1 = v1 ? k1 >> 16 : 0u;
-    uint32_t acc = 0;
-    if (v0 && v1) {
-        const float f0 = (float)d0, f1 = (float)d1;   // DMatch::distance is float
-        acc = (f0 < __fmul_rn(ratio, f1)) && !(f0 > dist_thresh);
-    }
-    KnnRow r;
-    r.idx = (v0 ? (k0 & 0xffffu) : 0xffffu) | ((v1 ? (k1 & 0xffffu) : 0xffffu) << 16);
-    r.d = d0 | (d1 << 9) | (acc << 18);
-    out[(size_t)pair * kcap + q] = r;
+    if (tid == 0) mcount[pair] = s_run;
 }
 
 // ---------------------------------------------------------------------------
@@ -1132,14 +1152,14 @@ void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, co
 }
 
 void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const int2 *pairs, int npairs, int kcap,
-                 uint2 *part, float dist_thresh, float ratio, KnnRow *out, hipEvent_t ev_mid)
+                 uint2 *part, float dist_thresh, float ratio, KnnRow *out, uint32_t *mlist, int *mcount, hipEvent_t ev_mid)
 {
     const int nchunks = (kcap + kKnnChunk - 1) / kKnnChunk;
     dim3 grid((kcap + 64 * kKnnQpl - 1) / (64 * kKnnQpl), nchunks, npairs);
     hipLaunchKernelGGL(k_knn2, grid, dim3(64), 0, st, desc, counts, pairs, kcap, nchunks, part);
     if (ev_mid) (void)hipEventRecord(ev_mid, st);
-    dim3 g2((kcap + 255) / 256, npairs);
-    hipLaunchKernelGGL(k_knn2_finalize, g2, dim3(256), 0, st, part, counts, pairs, kcap, nchunks, dist_thresh, ratio, out);
+    hipLaunchKernelGGL(k_knn2_finalize, dim3(npairs), dim3(1024), 0, st, part, counts, pairs, kcap, nchunks, dist_thresh, ratio, out, mlist,
+                       mcount);
 }
 
 void launch_bow_best2(hipStream_t st, const uint8_t *desc, const int *sets, int kcap, int ncams, const float *yv,
