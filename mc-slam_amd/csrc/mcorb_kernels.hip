@@ -295,19 +295,25 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     for (int attempt = 0; attempt < 2; attempt++) {
     // ---- pass 1: 4-point test, 4 horizontally adjacent pixels per lane: five aligned LDS dwords
     //      (centre, left, right, 3 rows up, 3 rows down) feed packed 16-bit min/max; survivors are
-    //      appended in raster order (lane-major, then byte position) ----
+    //      appended in raster order (lanes run row-major over the trip's rows, then byte position) ----
     int nA = 0;
     {
         const uint32_t *t32 = reinterpret_cast<const uint32_t *>(tile);
-        const int g0 = (ph + 3) >> 2, g1 = (ph + 2 + wi) >> 2, ng = g1 - g0 + 1;
-        const int nw = hi * ng;
-        const float rcp_ng = 1.0f / (float)ng;
+        const int g0 = (ph + 3) >> 2, g1 = (ph + 2 + wi) >> 2, ng = g1 - g0 + 1;   // 4-px groups per row, <= 19
         const int cmin = ph + 3, cmax = ph + 3 + wi;   // valid tile columns [cmin, cmax)
         const s16x2 zero = {0, 0};
-        for (int w0 = 0; w0 < nw; w0 += 64) {
-            const int wr = w0 + lane;
-            const int w = wr < nw ? wr : nw - 1;   // tail lanes redo the last item; their results are masked out
-            const int r = (int)(((float)w + 0.5f) * rcp_ng), gq = g0 + (w - r * ng);
+        // lane = (row within the trip) * ng + group: the column part of every address and the column validity are
+        // per-lane constants, a trip only advances the row (64 / ng rows per trip; lanes beyond that idle)
+        const int rpi = (int)(64.0f / (float)ng + 0.01f);
+        const int lr = (int)(((float)lane + 0.5f) / (float)ng), gq = g0 + (lane - lr * ng);
+        const bool lane_on = lr < rpi;
+        const int col = 4 * gq;   // only the first / last group of a row can hold columns outside [cmin, cmax)
+        const bool v0 = lane_on && col >= cmin && col < cmax, v1 = lane_on && col + 1 >= cmin && col + 1 < cmax;
+        const bool v2 = lane_on && col + 2 >= cmin && col + 2 < cmax, v3 = lane_on && col + 3 >= cmin && col + 3 < cmax;
+        for (int r0 = 0; r0 < hi; r0 += rpi) {
+            const int rq = r0 + lr;
+            const bool in = rq < hi;
+            const int r = in ? rq : hi - 1;   // rows past the end redo the last one; their results are masked out
             const int di = (r + 3) * nd + gq;
             const uint32_t C = t32[di], Cl = t32[di - 1], Cr = t32[di + 1], U = t32[di - 3 * nd], Dn = t32[di + 3 * nd];
             const uint32_t Lf = __builtin_amdgcn_alignbyte(C, Cl, 1);   // columns 4g-3 .. 4g
@@ -329,13 +335,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
                     __builtin_elementwise_min(__builtin_elementwise_max(d8, d12), __builtin_elementwise_max(d12, d0)));
                 mm[hgh] = __builtin_elementwise_max(lo, zero - hi2);
             }
-            // only the first / last group of a row can hold columns outside [cmin, cmax)
-            const int col = 4 * gq;
-            const bool in = wr < nw;
-            const bool c0 = in && mm[0].x > T && col >= cmin && col < cmax;
-            const bool c1 = in && mm[0].y > T && col + 1 >= cmin && col + 1 < cmax;
-            const bool c2 = in && mm[1].x > T && col + 2 >= cmin && col + 2 < cmax;
-            const bool c3 = in && mm[1].y > T && col + 3 >= cmin && col + 3 < cmax;
+            const bool c0 = in && v0 && mm[0].x > T;
+            const bool c1 = in && v1 && mm[0].y > T;
+            const bool c2 = in && v2 && mm[1].x > T;
+            const bool c3 = in && v3 && mm[1].y > T;
             const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1), b2 = __ballot(c2), b3 = __ballot(c3);
             int o = lane_rank(b3, lane_rank(b2, lane_rank(b1, lane_rank(b0, nA))));
             if (c0) work[o++] = (uint16_t)pos;
