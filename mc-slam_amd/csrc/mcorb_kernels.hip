@@ -220,6 +220,9 @@ __device__ __forceinline__ int fast_even8_max(const uint8_t *c, int TP)
     return best.x > best.y ? best.x : best.y;
 }
 
+// TPC: LDS row pitch of every cell of the launch (48 or 64 bytes; all 35-px cells of the usual resolutions fit 48), a
+// compile-time constant so that the ring / neighbour offsets fold into the ds_read offset fields; 0 = per-cell pitch.
+template <int TPC>
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom g, int iniTh, int minTh,
                                                    int tileBytes, uint32_t *__restrict__ cell_kp,
                                                    int *__restrict__ cell_cnt)
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     //      35-px cell costs one HBM round trip instead of eight ----
     const uint8_t *plane = pyr + (size_t)img * g.imgBytes + L.off;
     const int ph = iniX & 3;
-    const int nq = (ph + cols + 15) >> 4;   // 16-byte chunks per row, <= 3 for 35-px cells
+    const int nq = TPC ? TPC / 16 : (ph + cols + 15) >> 4;   // 16-byte chunks per row, <= 3 for 35-px cells
     const int nd = nq * 4;                  // dwords per LDS row
     const int TP = nq * 16;                 // LDS pitch of this cell
     {
@@ -1110,16 +1113,20 @@ void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, i
 {
     dim3 grid(g.cells, nimg);
     // LDS per cell: ROI rows x 16-byte-aligned pitch (3 phase bytes + wCell + 6), for the tile and for the score map
-    int tileBytes = 0;
+    int pitch = 0, rows = 0;
     for (int l = 0; l < g.nlevels; l++) {
-        const int tb = (g.lv[l].hCell + 6) * (((3 + g.lv[l].wCell + 6 + 15) >> 4) << 4);
-        tileBytes = tileBytes > tb ? tileBytes : tb;
+        const int p = ((3 + g.lv[l].wCell + 6 + 15) >> 4) << 4;
+        pitch = pitch > p ? pitch : p;
+        rows = rows > g.lv[l].hCell + 6 ? rows : g.lv[l].hCell + 6;
     }
-    tileBytes = (tileBytes + 15) & ~15;
+    const int tpc = pitch <= 48 ? 48 : (pitch <= 64 ? 64 : 0);   // one fixed pitch for the whole launch when it fits
+    const int tileBytes = (rows * (tpc ? tpc : pitch) + 15) & ~15;
     int maxNi = 0;   // interior pixels of a cell = worst-case length of the survivor list (u16 entries)
     for (int l = 0; l < g.nlevels; l++) maxNi = maxNi > g.lv[l].wCell * g.lv[l].hCell ? maxNi : g.lv[l].wCell * g.lv[l].hCell;
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(64), 2 * tileBytes + ((2 * maxNi + 15) & ~15), st, pyr, g, iniTh, minTh, tileBytes, cell_kp,
-                       cell_cnt);
+    const size_t lds = 2 * tileBytes + ((2 * maxNi + 15) & ~15);
+    if (tpc == 48) hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileBytes, cell_kp, cell_cnt);
+    else if (tpc == 64) hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileBytes, cell_kp, cell_cnt);
+    else hipLaunchKernelGGL(k_fast_cells<0>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileBytes, cell_kp, cell_cnt);
 }
 
 void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt, const Geom &g, uint32_t *sorted_dev,
