@@ -918,19 +918,20 @@ __device__ __forceinline__ void knn_insert(uint32_t key, uint32_t &k0, uint32_t 
 // kKnnQpl distance evaluations, which divides the LDS traffic per distance and gives each wave
 // kKnnQpl independent dependency chains.
 constexpr int kKnnQpl = 1;
+constexpr int kKnnWG = 256;   // threads per workgroup
 
-__global__ __launch_bounds__(64) void k_knn2(const uint8_t *__restrict__ desc, const int *__restrict__ counts,
+__global__ __launch_bounds__(kKnnWG) void k_knn2(const uint8_t *__restrict__ desc, const int *__restrict__ counts,
                                              const int2 *__restrict__ pairs, int kcap, int nchunks,
                                              uint2 *__restrict__ part)
 {
     __shared__ __attribute__((aligned(16))) ulonglong4 tr[kKnnChunk];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x;   // kKnnWG / 64 waves share one staged train chunk
     const int pair = blockIdx.z, chunk = blockIdx.y;
     const int2 qt = pairs[pair];
     const int nq = counts[qt.x], nt = counts[qt.y];
-    const int q0 = blockIdx.x * (64 * kKnnQpl) + lane;
+    const int q0 = blockIdx.x * (kKnnWG * kKnnQpl) + lane;
     const int t0 = chunk * kKnnChunk;
-    if (blockIdx.x * (64 * kKnnQpl) >= nq) return;
+    if (blockIdx.x * (kKnnWG * kKnnQpl) >= nq) return;
     uint32_t k0[kKnnQpl], k1[kKnnQpl];
 #pragma unroll
     for (int u = 0; u < kKnnQpl; u++) k0[u] = k1[u] = 0xffffffffu;
@@ -939,13 +940,13 @@ __global__ __launch_bounds__(64) void k_knn2(const uint8_t *__restrict__ desc, c
         // (fetching the wave-uniform train descriptor with scalar loads instead of LDS broadcasts was measured
         // slower: 125 vs 118 us -- the s_load latency is not hidden with four in flight per wave)
         const ulonglong4 *tsrc = reinterpret_cast<const ulonglong4 *>(desc + ((size_t)qt.y * kcap + t0) * 32);
-        for (int i = lane; i < tn; i += 64) tr[i] = tsrc[i];
+        for (int i = lane; i < tn; i += kKnnWG) tr[i] = tsrc[i];
         __syncthreads();
         ulonglong4 v[kKnnQpl];
 #pragma unroll
         for (int u = 0; u < kKnnQpl; u++) {
             v[u] = ulonglong4{0, 0, 0, 0};
-            if (q0 + 64 * u < nq) v[u] = *reinterpret_cast<const ulonglong4 *>(desc + ((size_t)qt.x * kcap + q0 + 64 * u) * 32);
+            if (q0 + kKnnWG * u < nq) v[u] = *reinterpret_cast<const ulonglong4 *>(desc + ((size_t)qt.x * kcap + q0 + kKnnWG * u) * 32);
         }
         auto step = [&](int j) {
             const ulonglong4 t = tr[j];
@@ -962,7 +963,7 @@ __global__ __launch_bounds__(64) void k_knn2(const uint8_t *__restrict__ desc, c
     uint2 *out = part + ((size_t)pair * nchunks + chunk) * kcap;
 #pragma unroll
     for (int u = 0; u < kKnnQpl; u++)
-        if (q0 + 64 * u < nq) out[q0 + 64 * u] = uint2{k0[u], k1[u]};
+        if (q0 + kKnnWG * u < nq) out[q0 + kKnnWG * u] = uint2{k0[u], k1[u]};
 }
 
 // Merge chunk partials, emit the knnMatch table and BruteForceMatch's accept
@@ -1165,8 +1166,8 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
                  uint2 *part, float dist_thresh, float ratio, KnnRow *out, uint32_t *mlist, int *mcount, hipEvent_t ev_mid)
 {
     const int nchunks = (kcap + kKnnChunk - 1) / kKnnChunk;
-    dim3 grid((kcap + 64 * kKnnQpl - 1) / (64 * kKnnQpl), nchunks, npairs);
-    hipLaunchKernelGGL(k_knn2, grid, dim3(64), 0, st, desc, counts, pairs, kcap, nchunks, part);
+    dim3 grid((kcap + kKnnWG * kKnnQpl - 1) / (kKnnWG * kKnnQpl), nchunks, npairs);
+    hipLaunchKernelGGL(k_knn2, grid, dim3(kKnnWG), 0, st, desc, counts, pairs, kcap, nchunks, part);
     if (ev_mid) (void)hipEventRecord(ev_mid, st);
     hipLaunchKernelGGL(k_knn2_finalize, dim3(npairs), dim3(1024), 0, st, part, counts, pairs, kcap, nchunks, dist_thresh, ratio, out, mlist,
                        mcount);
