@@ -177,12 +177,12 @@ __device__ __forceinline__ int fast_arc_max(const uint8_t *c, int TP)
     r[4] = c[3];         r[5] = c[-TP + 3];  r[6] = c[-T2 + 2];  r[7] = c[-T3 + 1];
     r[8] = c[-T3];       r[9] = c[-T3 - 1];  r[10] = c[-T2 - 2]; r[11] = c[-TP - 3];
     r[12] = c[-3];       r[13] = c[TP - 3];  r[14] = c[T2 - 2];  r[15] = c[T3 - 1];
+    // p[k] = (v - r[k], r[k] - v): replicate the ring byte into both halves (v_perm), then one v_pk_mad_i16
+    const s16x2 vv = {(short)v, (short)(-v)}, pm = {-1, 1};
     s16x2 p[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int d = v - r[k];
-        p[k] = s16x2{(short)d, (short)(-d)};
-    }
+    for (int k = 0; k < 16; k++)
+        p[k] = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, (uint32_t)r[k], 0x0c000c00u)) * pm + vv;
     s16x2 m2[16], m4[16], m8[16];
 #pragma unroll
     for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(p[k], p[(k + 1) & 15]);
@@ -205,12 +205,11 @@ __device__ __forceinline__ int fast_even8_max(const uint8_t *c, int TP)
     const int v = c[0];
     const int T2 = 2 * TP, T3 = 3 * TP;
     const int r[8] = {c[T3], c[T2 + 2], c[3], c[-T2 + 2], c[-T3], c[-T2 - 2], c[-3], c[T2 - 2]};
+    const s16x2 vv = {(short)v, (short)(-v)}, pm = {-1, 1};
     s16x2 e[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const int d = v - r[k];
-        e[k] = s16x2{(short)d, (short)(-d)};
-    }
+    for (int k = 0; k < 8; k++)
+        e[k] = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, (uint32_t)r[k], 0x0c000c00u)) * pm + vv;
     s16x2 m2[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) m2[k] = __builtin_elementwise_min(e[k], e[(k + 1) & 7]);
