@@ -244,7 +244,11 @@ int mcorb_rig_get_pair_knn2(mcorb_rig *r, int slot, int frame, int cam_i, int ca
     const int nq = s->match_counts[frame * r->rig.ncams + cam_i];
     if (nq_out) *nq_out = nq;
     if (nq > cap_rows) { set_error("knn buffer too small"); return MCORB_E_CAP; }
-    decode_rows(s->h_knn + (size_t)pi * r->rig.geom.kcap, nq, idx, dist);
+    // the k-NN rows stay on the device (the pipeline itself only needs the compacted accept lists): fetch on demand
+    std::vector<KnnRow> rows((size_t)std::max(nq, 1));
+    HIPCHK(hipSetDevice(r->rig.device));
+    if (nq) HIPCHK(hipMemcpy(rows.data(), s->d_knn + (size_t)pi * r->rig.geom.kcap, (size_t)nq * sizeof(KnnRow), hipMemcpyDeviceToHost));
+    decode_rows(rows.data(), nq, idx, dist);
     return MCORB_OK;
 }
 

@@ -424,7 +424,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         TRY(host_alloc(&s->h_lvloff, M * (kMaxLevels + 1)));
         TRY(host_alloc(&s->h_shipped, M * kMaxLevels));
         TRY(host_alloc(&s->h_overflow, 16));
-        TRY(host_alloc(&s->h_knn, (size_t)npairs_max * geom.kcap));
+        TRY(dev_alloc(&s->d_knn, (size_t)npairs_max * geom.kcap));
         TRY(host_alloc(&s->h_mlist, (size_t)npairs_max * geom.kcap));
         TRY(host_alloc(&s->h_mcount, (size_t)npairs_max));
         {
@@ -480,7 +480,7 @@ Rig::~Rig()
         (void)hipFree(s->d_pyr); (void)hipFree(s->d_blur); (void)hipFree(s->d_desc); (void)hipFree(s->d_cellkp);
         (void)hipFree(s->d_cellcnt); (void)hipFree(s->d_sorted); (void)hipHostFree(s->h_bstart); (void)hipHostFree(s->h_bbest); (void)hipFree(s->d_angles); (void)hipFree(s->d_part); (void)hipFree(s->d_f32);
         (void)hipHostFree(s->h_cand); (void)hipHostFree(s->h_lvloff); (void)hipHostFree(s->h_shipped); (void)hipHostFree(s->h_overflow);
-        (void)hipHostFree(s->h_knn); (void)hipHostFree(s->h_mlist); (void)hipHostFree(s->h_mcount); (void)hipHostFree(s->h_ctrl); (void)hipFree(s->d_ctrl);
+        (void)hipFree(s->d_knn); (void)hipHostFree(s->h_mlist); (void)hipHostFree(s->h_mcount); (void)hipHostFree(s->h_ctrl); (void)hipFree(s->d_ctrl);
         (void)hipHostFree(s->h_stage);
         (void)hipHostFree(s->h_desc); (void)hipHostFree(s->h_angles);
         for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
@@ -871,7 +871,7 @@ int Rig::enqueue_match(Slot &s, const Job &j, bool ctrl_on_device)
     const bool ext = j.ext_desc != nullptr;
     HIPCHK(hipEventRecord(s.ev[7], s.st));
     launch_knn2(s.st, ext ? (const uint8_t *)j.ext_desc : s.d_desc, ext ? s.d_extcounts : s.d_nsel, s.d_pairs,
-                s.npairs_done, geom.kcap, s.d_part, j.dist_thresh, j.ratio, s.h_knn, s.h_mlist, s.h_mcount, s.ev[8]);
+                s.npairs_done, geom.kcap, s.d_part, j.dist_thresh, j.ratio, s.d_knn, s.h_mlist, s.h_mcount, s.ev[8]);
     HIPCHK(hipEventRecord(s.ev[9], s.st));
     HIPCHK(hipGetLastError());
     return MCORB_OK;

@@ -99,7 +99,7 @@ struct Slot {
     int *h_shipped = nullptr;        // per (image, level): 1 if k_compact copied the level's candidate list to h_cand
     volatile uint32_t touch_sink[16] = {};
     BucketBest *h_bbest = nullptr;   // per bucket: winner of the final pick (k_compact)
-    KnnRow *h_knn = nullptr;
+    KnnRow *d_knn = nullptr;         // k-NN rows per pair (device; read back only by mcorb_rig_get_pair_knn2)
     uint32_t *h_mlist = nullptr;     // per pair: accepted (query << 16 | train), query order (k_knn2_finalize)
     int *h_mcount = nullptr;
     // control block: one pinned host buffer + one device mirror, copied with a single
