@@ -118,7 +118,20 @@ def main():
         if gloo:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            # RCCL prints a version banner on STDOUT when the communicator is created; stdout is reserved for the one JSON
+            # line, so the banner is sent to stderr (fd-level redirect around init + the first collective)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+                warm = torch.zeros(1, device="cuda")
+                dist.all_reduce(warm)
+                torch.cuda.synchronize()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
 
     F = args.frames if args.frames else (72 if DIST else 48)
     S = args.slots if args.slots else (9 if DIST else 6)
