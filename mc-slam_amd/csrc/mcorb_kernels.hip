@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
                                                   const uint32_t *__restrict__ sel, const int *__restrict__ nsel,
                                                   uint8_t *__restrict__ desc)
 {
-    __shared__ uint32_t patch[4][kDescPerWave][kPatchRows * kPatchDw];
+    __shared__ __attribute__((aligned(16))) uint32_t patch[4][kDescPerWave][kPatchRows * kPatchDw];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int img = blockIdx.y;
     const int k0 = (blockIdx.x * 4 + wave) * kDescPerWave;
@@ -781,11 +781,12 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
         const int bx = (kx - 13) & ~3;               // keypoints sit >= 19 px from every edge: window is in range
         shift[u] = kx - bx;                           // 13..16
         const uint8_t *src = blur + (size_t)img * g.imgBytes + L.off + (size_t)(ky - 13) * L.pitch + bx;
-#pragma unroll
-        for (int t = 0; t < (kPatchRows * kPatchDw + 63) / 64; t++) {
-            const int i = t * 64 + lane;
-            if (i < kPatchRows * kPatchDw)
-                patch[wave][u][i] = *reinterpret_cast<const uint32_t *>(src + (size_t)(i >> 3) * L.pitch + 4 * (i & 7));
+        // 27 rows x 32 bytes: one 16-byte load per lane (54 lanes), 4-byte aligned in HBM, 16-byte aligned in LDS
+        static_assert(kPatchDw == 8 && kPatchRows * 2 <= 64, "patch staging assumes 32-byte rows, two lanes per row");
+        struct __attribute__((packed, aligned(4))) Chunk { uint32_t a, b, c, d; };
+        if (lane < kPatchRows * 2) {
+            const Chunk v = *reinterpret_cast<const Chunk *>(src + (size_t)(lane >> 1) * L.pitch + 16 * (lane & 1));
+            *reinterpret_cast<uint4 *>(&patch[wave][u][lane * 4]) = uint4{v.a, v.b, v.c, v.d};
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
