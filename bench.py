@@ -85,8 +85,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=None, help="rig frames per rank per step (default 48; 72 on the N>1 path)")
-    ap.add_argument("--slots", type=int, default=None, help="buffer sets in flight per rank (default 6; 9 on the N>1 path)")
+    ap.add_argument("--frames", type=int, default=None, help="rig frames per rank per step (default 192; 128 on the N>1 path)")
+    ap.add_argument("--slots", type=int, default=None, help="buffer sets in flight per rank (default 6; 8 = 4 groups x 2 on the N>1 path)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-frames", type=int, default=24)
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (use when profiling kernels)")
@@ -133,10 +133,10 @@ def main():
                 os.dup2(saved, 1)
                 os.close(saved)
 
-    F = args.frames if args.frames else (72 if DIST else 48)
-    S = args.slots if args.slots else (9 if DIST else 6)
+    F = args.frames if args.frames else (128 if DIST else 192)   # N = 1: 6 slots x 32 rig frames = 128 images per launch
+    S = args.slots if args.slots else (8 if DIST else 6)
     S = max(1, min(S, F))
-    G = int(os.environ.get("MCORB_BENCH_GROUPS", "3")) if DIST else 1   # slot groups: with N > 1 G-1 groups extract steps k+1.. while one matches step k
+    G = int(os.environ.get("MCORB_BENCH_GROUPS", "4")) if DIST else 1   # slot groups: with N > 1 G-1 groups extract steps k+1.. while one matches step k
     if DIST and S % G:
         S += G - S % G
     SG = S // G                        # slots per group
@@ -175,6 +175,7 @@ def main():
             rig.extract_submit(per_slot, slot=g * SG + i)
 
     def exchange_and_match(g):
+        """Waits for group g's extraction, exchanges the descriptors and queues the matching; match_finish(g) collects it."""
         cnt_host = np.zeros(F * NCAMS, np.int32)
         for i in range(SG):
             s = g * SG + i
@@ -194,6 +195,8 @@ def main():
         counts = all_cnt[g].cpu().numpy()                       # syncs the collective
         for i in range(SG):                                     # this rank's frames, split over the group's slots
             rig.match_external_submit(all_desc[g].data_ptr(), counts, sets[i * fps:(i + 1) * fps], slot=g * SG + i)
+
+    def match_finish(g):
         for i in range(SG):
             rig.match_wait(slot=g * SG + i)
 
@@ -220,18 +223,32 @@ def main():
         """nsteps steps = nsteps*F frames per rank.
         N == 1: rolling submission, S jobs always in flight (a slot is resubmitted as soon as its previous job
         is collected), so step boundaries do not drain the pipeline.
-        N > 1: three slot groups rotate; extraction of steps k+1 and k+2 is in flight while step k's descriptors
+        N > 1: G slot groups rotate; extraction of steps k+1 .. k+G-2 is in flight while step k's descriptors
         are all-gathered and matched."""
         if DIST:
+            # step k runs on group k % G.  While step k's descriptors are exchanged, step k-1 is being matched and steps
+            # k+1 .. k+G-2 are being extracted; a group is re-armed (next extraction) as soon as its matching is collected.
+            def collect(g):
+                match_finish(g)
+                if timed:
+                    for i in range(SG):
+                        account(g * SG + i)
+            if G == 1:
+                for k in range(nsteps):
+                    extract_submit(0)
+                    exchange_and_match(0)
+                    collect(0)
+                return
             for k in range(min(G - 1, nsteps)):
                 extract_submit(k % G)
             for k in range(nsteps):
-                if k + G - 1 < nsteps:
-                    extract_submit((k + G - 1) % G)     # the group step k-1 was matched on: free again
                 exchange_and_match(k % G)
-                if timed:
-                    for i in range(SG):
-                        account((k % G) * SG + i)
+                if k >= 1:
+                    collect((k - 1) % G)
+                if k + G - 1 < nsteps:
+                    extract_submit((k + G - 1) % G)     # idle at k = 0, just collected afterwards
+            if nsteps >= 1:
+                collect((nsteps - 1) % G)
             return
         jobs = nsteps * S
         for s in range(min(S, jobs)):

@@ -25,12 +25,13 @@ def kib(path):
     return d
 
 
+NIMG = json.load(open(os.path.join(P, tag + "_bench_default.json")))["roofline"]["images_per_launch"]   # the one-slot runs use the same launch size
 f, w = kib(os.path.join(P, tag + "_pmc_fetch_size_summary.txt")), kib(os.path.join(P, tag + "_pmc_write_size_summary.txt"))
 old = json.load(open(os.path.join(P, "traffic.json")))
 out = {"_source": old["_source"]}
 for k in ("k_fast_cells", "k_blur", "k_knn2", "k_describe", "k_compact", "k_knn2_finalize"):
-    out[k] = {"bytes_per_image": int((f[k] + w[k]) * 1024 / 32), "fetch_kib_per_32_images": f[k], "write_kib_per_32_images": w[k]}
-out["k_resize"] = {"bytes_per_image": int((f["k_resize"] + w["k_resize"]) * 1024 * 7 / 32), "note": "sum of the 7 level launches",
+    out[k] = {"bytes_per_image": int((f[k] + w[k]) * 1024 / NIMG), "fetch_kib_per_launch": f[k], "write_kib_per_launch": w[k], "images_per_launch": NIMG}
+out["k_resize"] = {"bytes_per_image": int((f["k_resize"] + w["k_resize"]) * 1024 * 7 / NIMG), "note": "sum of the 7 level launches",
                    "fetch_kib_per_launch": f["k_resize"], "write_kib_per_launch": w["k_resize"]}
 json.dump(out, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 print("installed", tag)

@@ -409,3 +409,55 @@ def test_zero_copy_staging_equals_upload(mc):
         assert_same_features(ref[c], rig.features(c), "staged cam %d" % c)
     assert np.array_equal(rig.tracks(0)[0], tr_ref)
     rig.close()
+
+
+def test_sharded_path_export_gather_match_external(mc):
+    """The N > 1 data path of bench.py on one device: two virtual ranks extract their share of the cameras
+    ((c + f) mod 2), export their descriptor sets, the sets are concatenated as an all-gather would, and each rank
+    matches its frames (f mod 2) with mcorb_rig_match_external.  Tracks must equal the oracle's and the fused path's."""
+    import ctypes
+    from importlib import import_module
+    shard = import_module("mc-slam_amd.sharding")
+    hip = ctypes.CDLL("libamdhip64.so")          # the runtime libmcorb already loaded (torch would bring its own copy)
+    world, C, W, H, N, FPR = 2, 4, 640, 480, 800, 2          # 2 frames per rank per step
+    total = FPR * world
+    per = shard.sets_per_rank(world, C, total)
+    rigs = [mc.Rig(C, W, H, max_frames=FPR, nslots=1, nfeatures=N) for _ in range(world)]
+    kcap = rigs[0].kcap
+    nbytes = world * per * kcap * 32
+    gathered = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(gathered), ctypes.c_size_t(nbytes)) == 0
+    assert hip.hipMemset(gathered, 0, ctypes.c_size_t(nbytes)) == 0 and hip.hipDeviceSynchronize() == 0
+    counts = np.zeros(world * per, np.int32)
+    images = {}
+    for r in range(world):
+        mine = shard.images_of_rank(r, world, C, total)
+        assert len(mine) == per == FPR * C
+        imgs = [mc.synth_rig_frame(f, C, c, W, H) for (f, c) in mine]
+        for fc, im in zip(mine, imgs):
+            images[fc] = im
+        rigs[r].upload(imgs)
+        rigs[r].extract(per)
+        counts[r * per:(r + 1) * per] = rigs[r].export_descriptors(gathered.value + r * per * kcap * 32, per)
+    ora = {fc: O.OracleExtractor(N)(im) for fc, im in images.items()}
+    block = np.zeros((world * per, kcap, 32), np.uint8)
+    assert hip.hipMemcpy(ctypes.c_void_p(block.ctypes.data), gathered, ctypes.c_size_t(nbytes), 2) == 0   # hipMemcpyDeviceToHost
+    for fc, s in shard.gathered_set_index(world, C, total).items():
+        assert counts[s] == len(ora[fc][2]) and np.array_equal(block[s, :counts[s]], ora[fc][2]), fc
+    fused = mc.Rig(C, W, H, max_frames=1, nslots=1, nfeatures=N)
+    for r in range(world):
+        frames, sets = shard.match_sets(r, world, C, total)
+        rigs[r].match_external(gathered.value, counts, sets)
+        for i, f in enumerate(frames):
+            tr, mg = rigs[r].tracks(i)
+            otr, omg = O.intra_matches([ora[(f, c)][2] for c in range(C)])
+            assert np.array_equal(tr, otr) and mg == omg, (r, f)
+            fused.upload([images[(f, c)] for c in range(C)])
+            fused.process(1)
+            assert np.array_equal(fused.tracks(0)[0], tr)
+            g1, g2 = rigs[r].pair_matches(i, 0, 3)
+            o1, o2 = O.bruteforce_match(ora[(f, 0)][2], ora[(f, 3)][2])
+            assert np.array_equal(g1, o1) and np.array_equal(g2, o2)
+    for rg in rigs + [fused]:
+        rg.close()
+    hip.hipFree(gathered)
