@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--frames", type=int, default=None, help="rig frames per rank per step (default 192; 128 on the N>1 path)")
     ap.add_argument("--slots", type=int, default=None, help="buffer sets in flight per rank (default 6; 8 = 4 groups x 2 on the N>1 path)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-frames", type=int, default=24)
+    ap.add_argument("--cpu-frames", type=int, default=48, help="rig frames timed on the CPU oracle (about 12 s of CPU work on 4 threads)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (use when profiling kernels)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); 'gloo' only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses device 0")
