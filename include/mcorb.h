@@ -32,7 +32,7 @@ extern "C" {
 #define MCORB_E_HIP (-5)       /* HIP runtime error, see mcorb_last_error() */
 #define MCORB_E_NODEVICE (-6)  /* no usable gfx950 device */
 #define MCORB_E_STATE (-7)     /* call out of order (e.g. match before extract) */
-#define MCORB_E_OVERFLOW (-8)  /* internal candidate buffer overflow (raise cand_cap) */
+#define MCORB_E_OVERFLOW (-8)  /* a sparse level's candidate list does not fit the host buffer (raise cand_cap) */
 
 #define MCORB_MAX_LEVELS 16
 #define MCORB_MAX_CAMS 16      /* IntraMatch::matchIndex is array<int,5> in the reference
@@ -57,7 +57,8 @@ typedef struct mcorb_params {
     int orientation;      /* MCORB_ORIENT_* */
     int device_id;        /* HIP device ordinal */
     int host_threads;     /* selection workers; 0 = one per camera image, capped at hw concurrency */
-    int cand_cap;         /* FAST candidates kept per image; 0 = default (max(65536, w*h/4)) */
+    int cand_cap;         /* host-side candidate slots per image (the device list is sized for the worst case);
+                             only sparse levels are copied to the host; 0 = default (max(65536, w*h/4)) */
     int reserved[7];
 } mcorb_params;
 

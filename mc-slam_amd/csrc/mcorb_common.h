@@ -62,7 +62,8 @@ struct Geom {
     int cellCap;          // keypoint slots per cell in the scratch array
     uint32_t imgBytes;    // bytes of one image's pyramid block
     int kcap;             // keypoint capacity per image
-    int candCap;          // candidate capacity per image
+    int candCap;          // candidates per image in the device list (worst case: cells * cellCap)
+    int hostCandCap;      // capacity of the host copy per image (mcorb_params.cand_cap)
     int bucketTotal;      // bucket-start entries per image, all levels
     LevelGeom lv[kMaxLevels];
 };

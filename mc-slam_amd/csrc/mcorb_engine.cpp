@@ -183,8 +183,13 @@ int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g
     g.kcap = (int)align_up((size_t)p.nfeatures + 4 * t.nlevels + 48, 64);
     if (g.kcap > 65535) { set_error("nfeatures too large (k-NN index is 16 bits)"); return MCORB_E_ARG; }
     // default: one candidate slot per 4 level-0 pixels (measured: ~1 per 28 px on the synthetic rig frames)
-    g.candCap = p.cand_cap > 0 ? p.cand_cap : (int)align_up(std::max((size_t)65536, (size_t)W * H / 4), 4096);
-    if (g.candCap > kPickOrderMask) { set_error("cand_cap too large (pick order is 23 bits)"); return MCORB_E_ARG; }
+    // device list: worst case (every cell full: one corner per 2x2 px survives the 3x3 NMS at most), so FAST itself can
+    // never overflow; host copy: one slot per 4 level-0 pixels by default (~1 per 28 px measured on the synthetic rig
+    // frames) -- it is only written when the quad-tree may go below the bucketing, i.e. for sparse levels
+    g.candCap = (int)align_up((size_t)g.cells * g.cellCap, 4096);
+    g.hostCandCap = p.cand_cap > 0 ? p.cand_cap : (int)align_up(std::max((size_t)65536, (size_t)W * H / 4), 4096);
+    if (g.hostCandCap > g.candCap) g.hostCandCap = g.candCap;
+    if (g.lv[0].nCols * g.lv[0].nRows * g.cellCap > kPickOrderMask) { set_error("image too large (pick order is 23 bits)"); return MCORB_E_SIZE; }
     return MCORB_OK;
 }
 
@@ -420,7 +425,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         HIPCHK(hipMemset(s->d_desc, 0, M * geom.kcap * 32));
         TRY(dev_alloc(&s->d_angles, M * geom.kcap));
         TRY(dev_alloc(&s->d_part, (size_t)npairs_max * nchunks * geom.kcap));
-        TRY(host_alloc(&s->h_cand, M * geom.candCap));
+        TRY(host_alloc(&s->h_cand, M * geom.hostCandCap));
         TRY(host_alloc(&s->h_lvloff, M * (kMaxLevels + 1)));
         TRY(host_alloc(&s->h_shipped, M * kMaxLevels));
         TRY(host_alloc(&s->h_overflow, 16));
@@ -690,7 +695,7 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
 {
     HIPCHK(hipEventSynchronize(s.ev[3]));
     if (s.h_overflow[0]) {
-        set_error("FAST candidate buffer overflow (raise mcorb_params.cand_cap)");
+        set_error("candidate list of a sparse level does not fit the host buffer (raise mcorb_params.cand_cap)");
         (void)hipStreamSynchronize(s.st);
         return MCORB_E_OVERFLOW;
     }
@@ -721,7 +726,7 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
             // demand load per cache line instead of taking the misses one by one below (software prefetches were
             // measured slower, most get dropped)
             uint32_t touch = 0;
-            const uint32_t *c = s.h_cand + (size_t)m * geom.candCap;
+            const uint32_t *c = s.h_cand + (size_t)m * geom.hostCandCap;
             const uint32_t *b1 = reinterpret_cast<const uint32_t *>(s.h_bstart + (size_t)m * geom.bucketTotal);
             const uint32_t *b2 = reinterpret_cast<const uint32_t *>(s.h_bbest + (size_t)m * geom.bucketTotal);
             for (int l = 0; l < L; l++) {
@@ -744,7 +749,7 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
             idx.resize(out.size());
             int r = 0;
             if (n > 0)
-                r = select_octree(shp[level] ? s.h_cand + (size_t)m * geom.candCap + lo[level] : nullptr,
+                r = select_octree(shp[level] ? s.h_cand + (size_t)m * geom.hostCandCap + lo[level] : nullptr,
                                   s.h_bstart + (size_t)m * geom.bucketTotal + geom.lv[level].bucket0,
                                   s.h_bbest + (size_t)m * geom.bucketTotal + geom.lv[level].bucket0, n, selp[level],
                                   idx.data(), out.data(), *scratch[w]);

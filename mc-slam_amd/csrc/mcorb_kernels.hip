@@ -563,10 +563,14 @@ __global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ c
     // The list itself goes over PCIe only when the host can need it: DistributeOctTree divides a depth-D node (one
     // bucket) only after every node reached depth D with fewer than N nodes in total, and at that point the node count
     // equals the number of non-empty buckets.  With nz >= N the host works from bstart/bbest alone.
-    const bool ship = s_nz < L.quota;
+    bool ship = s_nz < L.quota;
+    if (ship && base + T > g.hostCandCap) {   // the host copy is smaller than the device list: tell the host instead of truncating
+        ship = false;
+        if (tid == 0) atomicOr(overflow, 1);
+    }
     if (tid == 0) shipped[(size_t)img * kMaxLevels + level] = ship ? 1 : 0;
     if (ship) {
-        uint32_t *dst = cand + (size_t)img * g.candCap + base;
+        uint32_t *dst = cand + (size_t)img * g.hostCandCap + base;
         for (int i = tid; i < T; i += 1024) dst[i] = sd[i];   // coalesced copy-out into host-mapped memory
     }
 }

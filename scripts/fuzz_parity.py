@@ -1,0 +1,79 @@
+"""Randomised differential test: random image sizes / contents / extractor parameters, GPU path against the CPU oracle,
+every keypoint field and descriptor byte.  usage: python3 scripts/fuzz_parity.py [ncases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import mcorb  # noqa: E402
+import oracle_lib as O  # noqa: E402
+
+
+def content(rng, W, H):
+    kind = rng.integers(0, 6)
+    base = mcorb.synth_rig_frame(int(rng.integers(0, 1000)), 1, 0, W, H).astype(np.int32)
+    if kind == 1:
+        base = (base - 128) // int(rng.integers(2, 12)) + 128                      # low contrast
+    elif kind == 2:
+        base = base + rng.integers(-40, 41, (H, W))                                # noisy
+    elif kind == 3:
+        base = np.full((H, W), 128) ; y0, x0 = rng.integers(20, H // 2), rng.integers(20, W // 2)
+        base[y0:y0 + H // 3, x0:x0 + W // 3] = rng.integers(0, 256, (H // 3, W // 3))   # clustered corners
+    elif kind == 4:
+        base = np.kron(rng.integers(0, 2, (H // 40 + 1, W // 40 + 1)) * 255, np.ones((40, 40), np.int64))[:H, :W]
+    elif kind == 5:
+        base = rng.integers(0, 256, (H, W))                                        # pure noise
+    return np.clip(base, 0, 255).astype(np.uint8), int(kind)
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    bad = 0
+    for case in range(ncases):
+        W, H = int(rng.integers(160, 1700)), int(rng.integers(120, 1200))
+        if W > 2.4 * H:
+            W = int(2.4 * H)
+        if H > 1.4 * W:
+            H = int(1.4 * W)
+        nf = int(rng.integers(50, 3500))
+        sf = float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.3, 1.5, 2.0]))
+        nl = int(rng.integers(1, 10))
+        ini, mn = int(rng.integers(5, 40)), int(rng.integers(3, 25))
+        img, kind = content(rng, W, H)
+        tag = "case %d: %dx%d kind %d nf %d sf %.1f nl %d th %d/%d" % (case, W, H, kind, nf, sf, nl, ini, mn)
+        try:
+            ora = O.OracleExtractor(nf, sf, nl, ini, mn)
+            ref = ora(img, cap=nf + 64 * nl + 4096)
+        except Exception as e:
+            print(tag, "oracle refused:", e)
+            continue
+        try:
+            ext = mcorb.ORBextractor(nf, sf, nl, ini, mn)
+            got = ext(img)
+            ext.close()
+        except Exception as e:
+            if ref[0] == -2 or "too small" in str(e) or "too tall" in str(e) or "too wide" in str(e):
+                print(tag, "both refuse / size limit:", str(e)[:60])
+                continue
+            print(tag, "GPU ERROR", e); bad += 1
+            continue
+        (m1, k1, d1), (m2, k2, d2) = ref, got
+        if m1 < 0:
+            print(tag, "oracle status", m1, "but GPU returned", m2)
+            bad += m1 != m2
+            continue
+        ok = m1 == m2 and len(k1) == len(k2) and all(np.array_equal(k1[f], k2[f]) for f in k1.dtype.names) and np.array_equal(d1, d2)
+        if not ok:
+            bad += 1
+            print(tag, "MISMATCH", m1, m2, len(k1), len(k2))
+        elif case % 10 == 0:
+            print(tag, "ok,", len(k1), "keypoints", flush=True)
+    print("fuzz: %d cases, %d bad" % (ncases, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

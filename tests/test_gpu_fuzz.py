@@ -1,0 +1,17 @@
+"""Randomised differential test (scripts/fuzz_parity.py): random sizes, contents (texture, low contrast, noise, clustered
+corners, blocks) and extractor parameters, every keypoint field and descriptor byte against the CPU oracle."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [3, 11])
+def test_randomised_parity(seed):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "40", str(seed)], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "0 bad" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
