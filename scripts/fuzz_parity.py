@@ -28,9 +28,56 @@ def content(rng, W, H):
     return np.clip(base, 0, 255).astype(np.uint8), int(kind)
 
 
+def rig_cases(ncases, rng):
+    """Random rigs: camera count, size, feature budget, match threshold / ratio; pair lists and tracks against the oracle."""
+    bad = 0
+    for case in range(ncases):
+        C = int(rng.integers(2, 7))
+        W, H = int(rng.integers(320, 900)), int(rng.integers(240, 640))
+        nf = int(rng.integers(200, 1500))
+        thr, ratio = float(rng.integers(30, 110)), float(rng.choice([0.6, 0.7, 0.85, 0.95, 1.0]))
+        frame = int(rng.integers(0, 500))
+        tag = "rig case %d: %d cams %dx%d nf %d thr %.0f ratio %.2f" % (case, C, W, H, nf, thr, ratio)
+        imgs = [mcorb.synth_rig_frame(frame, C, c, W, H) for c in range(C)]
+        if rng.random() < 0.3:   # one camera sees noise: few matches, different counts per camera
+            imgs[int(rng.integers(0, C))] = rng.integers(0, 256, (H, W)).astype(np.uint8)
+        try:
+            rig = mcorb.Rig(C, W, H, 1, 1, nfeatures=nf)
+        except Exception as e:   # sizes the reference's cell / root-node arithmetic cannot handle (MCORB_E_SIZE); the oracle says -2
+            assert "error -2" in str(e) and O.OracleExtractor(nf)(imgs[0])[0] == -2, (tag, e)
+            print(tag, "both refuse:", str(e)[:50])
+            continue
+        rig.upload(imgs)
+        rig.process(1, dist_thresh=thr, ratio=ratio)
+        ora = [O.OracleExtractor(nf)(im, cap=nf + 4096) for im in imgs]
+        ok = True
+        for c in range(C):
+            m, k, d = rig.features(c)
+            ok &= m == ora[c][0] and np.array_equal(d, ora[c][2]) and all(np.array_equal(k[f], ora[c][1][f]) for f in k.dtype.names)
+        for i in range(C - 1):
+            for j in range(i + 1, C):
+                g1, g2 = rig.pair_matches(0, i, j)
+                o1, o2 = O.bruteforce_match(ora[i][2], ora[j][2], thr, ratio)
+                ok &= np.array_equal(g1, o1) and np.array_equal(g2, o2)
+        tr, mg = rig.tracks(0)
+        otr, omg = O.intra_matches([o[2] for o in ora], thr, ratio)
+        ok &= np.array_equal(tr, otr) and mg == omg
+        rig.close()
+        if not ok:
+            bad += 1
+            print(tag, "MISMATCH")
+        elif case % 5 == 0:
+            print(tag, "ok,", len(tr), "tracks", flush=True)
+    return bad
+
+
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    if len(sys.argv) > 3 and sys.argv[3] == "rig":
+        bad = rig_cases(ncases, rng)
+        print("fuzz: %d cases, %d bad" % (ncases, bad))
+        return 1 if bad else 0
     bad = 0
     for case in range(ncases):
         W, H = int(rng.integers(160, 1700)), int(rng.integers(120, 1200))

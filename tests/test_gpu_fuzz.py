@@ -15,3 +15,10 @@ def test_randomised_parity(seed):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "40", str(seed)], capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "0 bad" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
+@pytest.mark.gpu
+def test_randomised_rig_parity():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "12", "5", "rig"], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "0 bad" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
