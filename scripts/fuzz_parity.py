@@ -89,16 +89,17 @@ def main():
         sf = float(rng.choice([1.1, 1.2, 1.2, 1.2, 1.3, 1.5, 2.0]))
         nl = int(rng.integers(1, 10))
         ini, mn = int(rng.integers(5, 40)), int(rng.integers(3, 25))
+        orient = int(os.environ.get("FUZZ_ORIENT", "0")) and int(rng.integers(0, 2))   # IC-angle mode (not the reference's default)
         img, kind = content(rng, W, H)
-        tag = "case %d: %dx%d kind %d nf %d sf %.1f nl %d th %d/%d" % (case, W, H, kind, nf, sf, nl, ini, mn)
+        tag = "case %d: %dx%d kind %d nf %d sf %.1f nl %d th %d/%d orient %d" % (case, W, H, kind, nf, sf, nl, ini, mn, orient)
         try:
-            ora = O.OracleExtractor(nf, sf, nl, ini, mn)
+            ora = O.OracleExtractor(nf, sf, nl, ini, mn, orient)
             ref = ora(img, cap=nf + 64 * nl + 4096)
         except Exception as e:
             print(tag, "oracle refused:", e)
             continue
         try:
-            ext = mcorb.ORBextractor(nf, sf, nl, ini, mn)
+            ext = mcorb.ORBextractor(nf, sf, nl, ini, mn, orient)
             got = ext(img)
             ext.close()
         except Exception as e:

@@ -10,10 +10,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", [3, 11])
-def test_randomised_parity(seed):
+@pytest.mark.parametrize("seed,orient", [(3, "0"), (11, "0"), (21, "1")])
+def test_randomised_parity(seed, orient):
+    """orient = 1 mixes in the IC-angle orientation mode (MCORB_ORIENT_IC_ANGLE, the reference's dormant IC_Angle)."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "40", str(seed)], capture_output=True,
-                         text=True, timeout=600)
+                         text=True, timeout=600, env=dict(os.environ, FUZZ_ORIENT=orient))
     assert out.returncode == 0 and "0 bad" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
 
 
