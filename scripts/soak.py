@@ -1,0 +1,65 @@
+"""Stability check: many create/destroy cycles (leaks, teardown races) and a long run of mixed synchronous / asynchronous
+calls on several slots from two threads; results must stay identical throughout."""
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import mcorb  # noqa: E402
+
+C, W, H = 4, 640, 480
+imgs = [mcorb.synth_rig_frame(1, C, c, W, H) for c in range(C)]
+
+
+def signature(rig, slot, frame=0):
+    tr, mg = rig.tracks(frame, slot=slot)
+    return int(tr.sum()) * 31 + mg + sum(int(rig.features(frame * C + c, slot=slot)[2].sum()) for c in range(C))
+
+
+t0 = time.time()
+ref = None
+for k in range(40):   # create / use / destroy
+    rig = mcorb.Rig(C, W, H, max_frames=2, nslots=3, nfeatures=700)
+    rig.upload(imgs + imgs, slot=k % 3)
+    rig.process(2, slot=k % 3)
+    s = signature(rig, k % 3), signature(rig, k % 3, 1)
+    assert s[0] == s[1]
+    ref = ref or s
+    assert s == ref, (k, s, ref)
+    rig.close()
+print("create/destroy x40 ok, %.1f s" % (time.time() - t0))
+
+rig = mcorb.Rig(C, W, H, max_frames=2, nslots=4, nfeatures=700)
+for s in range(4):
+    rig.upload(imgs + imgs, slot=s)
+errors = []
+
+
+def worker(slots, n):
+    try:
+        for k in range(n):
+            for s in slots:
+                if k % 2:
+                    rig.process_submit(2, slot=s)
+                else:
+                    rig.process(2, slot=s)
+            for s in slots:
+                if k % 2:
+                    rig.process_wait(slot=s)
+                assert signature(rig, s) == ref[0], (k, s)
+    except Exception as e:   # noqa: BLE001
+        errors.append(e)
+
+
+t0 = time.time()
+th = [threading.Thread(target=worker, args=(sl, 150)) for sl in ((0, 1), (2, 3))]
+for t in th:
+    t.start()
+for t in th:
+    t.join()
+assert not errors, errors
+print("2 threads x 150 rounds x 2 slots (sync + async mixed) ok, %.1f s" % (time.time() - t0))
+rig.close()

@@ -23,3 +23,10 @@ def test_randomised_rig_parity():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "12", "5", "rig"], capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "0 bad" in out.stdout, out.stdout[-2000:] + out.stderr[-1000:]
+
+
+@pytest.mark.gpu
+def test_soak_create_destroy_and_threads():
+    """scripts/soak.py: 40 create/use/destroy cycles, then two threads mixing synchronous and asynchronous calls on four slots."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "soak.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "x40 ok" in out.stdout and "mixed) ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
