@@ -124,20 +124,47 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
     }
     const uint32_t mask = dx4 + 4 > D.w ? 0xffffffffu >> (8 * (dx4 + 4 - D.w)) : 0xffffffffu;   // keep the row padding zero
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the row taps become scalar loads
+    // Each wave produces 4 CONSECUTIVE output rows.  Consecutive rows share source rows (s1 of row j is s0 of row j+1
+    // five times out of six at scale 1.2), so the horizontal two-tap sums R = S[s0]*a0 + S[s1]*a1 are kept per source
+    // row in two register sets and computed once (the row indices are wave-uniform: the reuse tests are scalar branches).
+    int rowA = -1, rowB = -1;
+    int HA[4], HB[4];
+    auto hrow = [&](int sr, int *Hout) {
+        const uint8_t *S = win + (sr - sy0) * srcPitch;
+#pragma unroll
+        for (int k = 0; k < 4; k++) Hout[k] = (S[s0[k]] * a0[k] + S[s1[k]] * a1[k]) >> 4;
+    };
 #pragma unroll
     for (int rr = 0; rr < kResizeRows / 4; rr++) {
-        const int dy = by0 + wave + 4 * rr;
+        const int dy = by0 + wave * (kResizeRows / 4) + rr;
         if (dy >= D.h) break;
         const ResizeTap ty = tabs[D.ytab + dy];
-        const uint8_t *S0 = win + (ty.s0 - sy0) * srcPitch;
-        const uint8_t *S1 = win + (ty.s1 - sy0) * srcPitch;
+        const int r0 = ty.s0, r1 = ty.s1;
+        // invariant after this block: HA holds source row r0, HB holds source row r1 (register moves, no selects)
+        if (r0 != rowA) {
+            if (r0 == rowB) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) HA[k] = HB[k];
+            } else {
+                hrow(r0, HA);
+            }
+            rowA = r0;
+        }
+        if (r1 != rowB) {
+            if (r1 == rowA) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) HB[k] = HA[k];
+            } else {
+                hrow(r1, HB);
+            }
+            rowB = r1;
+        }
+        const int *H0 = HA, *H1 = HB;
         const int b0 = ty.c0, b1 = ty.c1;
         uint32_t out = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int R0 = S0[s0[k]] * a0[k] + S0[s1[k]] * a1[k];
-            const int R1 = S1[s0[k]] * a0[k] + S1[s1[k]] * a1[k];
-            const int v = (((b0 * (R0 >> 4)) >> 16) + ((b1 * (R1 >> 4)) >> 16) + 2) >> 2;
+            const int v = (((b0 * H0[k]) >> 16) + ((b1 * H1[k]) >> 16) + 2) >> 2;
             out |= (uint32_t)(v & 0xff) << (8 * k);
         }
         *reinterpret_cast<uint32_t *>(base + D.off + (size_t)dy * D.pitch + dx4) = out & mask;
