@@ -179,20 +179,19 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
 // For a pixel v with ring r[0..15], d[k] = v - r[k]:
 //   A = max over the 16 contiguous 9-arcs of min(d) (dark) or min(-d) (bright)
 // p is a FAST corner at threshold t  <=>  A > t, and cornerScore = A - 1
-// independently of t.  So one pass computes A for every pixel; the reference's
-// "retry the cell with minThFAST if iniThFAST gave no keypoint" is a second
-// NMS pass over the same A map.  The dark and bright arcs are evaluated
-// together in packed 16-bit lanes (v_pk_min_i16 / v_pk_max_i16).
+// independently of t.  The dark and bright arcs are evaluated together in
+// packed 16-bit lanes (v_pk_min_i16 / v_pk_max_i16).  The three passes below
+// run at t = iniThFAST and, only when the cell came out empty, once more at
+// minThFAST (the reference's second cv::FAST call on the same ROI).
 // ---------------------------------------------------------------------------
 // One WAVE per cell (workgroup = 64 threads): every phase is wave-synchronous, so there is no
 // s_barrier anywhere and up to 32 cells are in flight per CU to hide LDS/HBM latency.
-//   pass 1  necessary condition at the lower threshold on every interior pixel (5 LDS bytes):
+//   pass 1  necessary condition on every interior pixel, 4 px per lane (5 LDS dwords):
 //           any 9-arc of the 16-ring holds two neighbouring compass points (k, k+4), so a corner
 //           needs such a pair both darker or both brighter than the centre by more than t;
 //   pass 2  survivors (ballot + popcount compaction into an LDS work list) get the full arc score, 64 at a time;
 //   pass 3  3x3 NMS on the score map, keypoints emitted straight to the cell's slot in raster
-//           order (running wave-uniform offset += popcount(ballot)); if the cell produced nothing
-//           at iniTh the pass is repeated at minTh (the reference's second cv::FAST call).
+//           order (running wave-uniform offset += popcount(ballot)).
 __device__ __forceinline__ int fast_arc_max(const uint8_t *c, int TP)
 {
     // ring offsets (dx,dy), k = 0..15 (cv::FAST makeOffsets, patternSize 16)
