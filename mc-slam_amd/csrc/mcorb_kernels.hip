@@ -172,79 +172,58 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
 }
 
 // ---------------------------------------------------------------------------
-// FAST-9/16 corner score + cell-local 3x3 non-max suppression, one workgroup
-// per 35-px cell (ComputeKeyPointsOctTree detection loop, ORBextractor.cpp:
-// 804-871, calling cv::FAST on each cell ROI).
+// FAST-9/16 corner score + cell-local 3x3 non-max suppression per 35-px cell
+// (ComputeKeyPointsOctTree detection loop, ORBextractor.cpp:804-871, calling
+// cv::FAST on each cell ROI).
 //
-// For a pixel v with ring r[0..15], d[k] = v - r[k]:
-//   A = max over the 16 contiguous 9-arcs of min(d) (dark) or min(-d) (bright)
+// For a pixel v with ring r[0..15]:
+//   A = max( v - min over the 16 contiguous 9-arcs of max(r in arc),      (dark)
+//            max over the 16 contiguous 9-arcs of min(r in arc) - v )     (bright)
 // p is a FAST corner at threshold t  <=>  A > t, and cornerScore = A - 1
-// independently of t.  The dark and bright arcs are evaluated together in
-// packed 16-bit lanes (v_pk_min_i16 / v_pk_max_i16).  The three passes below
-// run at t = iniThFAST and, only when the cell came out empty, once more at
-// minThFAST (the reference's second cv::FAST call on the same ROI).
+// independently of t.  Everything runs at t = iniThFAST first and, only for the
+// cells that came out empty, once more at minThFAST (the reference's second
+// cv::FAST call on the same ROI).
+//
+// One WAVE per workgroup, NC cells per wave (their survivor lists are pooled so that the 64-lane
+// trips of passes 2 and 3 are filled); every phase is wave-synchronous: no s_barrier anywhere.
+//   stage   ROI rows -> LDS as one u16 per pixel (row = lane, 16-byte global loads, all issued before
+//           the first LDS store), so that every later LDS read IS a packed-i16 operand (no unpacking)
+//   pass 1  necessary condition on every interior pixel, 4 px per lane (five ds_read_b64): a 9-arc of
+//           the 16-ring holds two NEIGHBOURING compass points; a compass point of the pair (up, down)
+//           is a ring neighbour of either point of (left, right), hence
+//             bright:  min(max(U,D), max(L,R)) > v + t      dark:  max(min(U,D), min(L,R)) < v - t
+//           survivors are appended to the work list in raster order (ballots + mbcnt ranks)
+//   pass 2  full arc score of the survivors, 64 at a time, on ring values packed as (r[k], r[k+8]):
+//           suffix / prefix minima and maxima of the two 8-blocks give all 16 nine-windows
+//           (window k = suffix_k of one block + prefix_k of the other), 60 packed min/max in all;
+//           the score map receives A where A > t and 0 elsewhere
+//   pass 3  3x3 NMS over the work list (already in raster order = cv::FAST's output order),
+//           keypoints emitted straight to the cell's slot.
 // ---------------------------------------------------------------------------
-// One WAVE per cell (workgroup = 64 threads): every phase is wave-synchronous, so there is no
-// s_barrier anywhere and up to 32 cells are in flight per CU to hide LDS/HBM latency.
-//   pass 1  necessary condition on every interior pixel, 4 px per lane (5 LDS dwords):
-//           any 9-arc of the 16-ring holds two neighbouring compass points (k, k+4), so a corner
-//           needs such a pair both darker or both brighter than the centre by more than t;
-//   pass 2  survivors (ballot + popcount compaction into an LDS work list) get the full arc score, 64 at a time;
-//   pass 3  3x3 NMS on the score map, keypoints emitted straight to the cell's slot in raster
-//           order (running wave-uniform offset += popcount(ballot)).
-__device__ __forceinline__ int fast_arc_max(const uint8_t *c, int TP)
-{
-    // ring offsets (dx,dy), k = 0..15 (cv::FAST makeOffsets, patternSize 16)
-    const int v = c[0];
-    const int T2 = 2 * TP, T3 = 3 * TP;
-    int r[16];
-    r[0] = c[T3];        r[1] = c[T3 + 1];   r[2] = c[T2 + 2];   r[3] = c[TP + 3];
-    r[4] = c[3];         r[5] = c[-TP + 3];  r[6] = c[-T2 + 2];  r[7] = c[-T3 + 1];
-    r[8] = c[-T3];       r[9] = c[-T3 - 1];  r[10] = c[-T2 - 2]; r[11] = c[-TP - 3];
-    r[12] = c[-3];       r[13] = c[TP - 3];  r[14] = c[T2 - 2];  r[15] = c[T3 - 1];
-    // p[k] = (v - r[k], r[k] - v): replicate the ring byte into both halves (v_perm), then one v_pk_mad_i16
-    const s16x2 vv = {(short)v, (short)(-v)}, pm = {-1, 1};
-    s16x2 p[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-        p[k] = __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, (uint32_t)r[k], 0x0c000c00u)) * pm + vv;
-    s16x2 m2[16], m4[16], m8[16];
-#pragma unroll
-    for (int k = 0; k < 16; k++) m2[k] = __builtin_elementwise_min(p[k], p[(k + 1) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) m4[k] = __builtin_elementwise_min(m2[k], m2[(k + 2) & 15]);
-#pragma unroll
-    for (int k = 0; k < 16; k++) m8[k] = __builtin_elementwise_min(m4[k], m4[(k + 4) & 15]);
-    s16x2 best = __builtin_elementwise_min(m8[0], p[8]);
-#pragma unroll
-    for (int k = 1; k < 16; k++) best = __builtin_elementwise_max(best, __builtin_elementwise_min(m8[k], p[(k + 8) & 15]));
-    const int a = best.x > best.y ? best.x : best.y;
-    return a < 0 ? 0 : a;   // <= 255
-}
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
-// TPC: LDS row pitch of every cell of the launch (48 or 64 bytes; all 35-px cells of the usual resolutions fit 48), a
-// compile-time constant so that the ring / neighbour offsets fold into the ds_read offset fields; 0 = per-cell pitch.
-template <int TPC>
-__global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom g, int iniTh, int minTh,
-                                                   int tileBytes, uint32_t *__restrict__ cell_kp,
-                                                   int *__restrict__ cell_cnt)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];   // tile | score map | work list
-    uint8_t *tile = lds;
-    uint8_t *sc = lds + tileBytes;
-    uint16_t *work = reinterpret_cast<uint16_t *>(lds + 2 * tileBytes);
+struct FastCell {      // wave-uniform description of one cell
+    int on;            // evaluated (not skipped by the reference's border rule, not degenerate)
+    int cell;          // cell index inside the image
+    int ph;            // byte phase of the ROI's first column in HBM (iniX & 3) = its column in the LDS tile
+    int wi, hi;        // evaluated columns / rows (ROI minus FAST's 3-px margin)
+    int rows;          // ROI rows
+    int g0, ng;        // first 4-px group holding an evaluated column, number of such groups
+    uint32_t org;      // pack_cand(cj*wCell - ph, ci*hCell, 0) mod 2^32: tile (col, row) -> candidate record
+    const uint8_t *src;   // first staged byte (ROI row 0, column iniX - ph)
+    int pitch;         // HBM row pitch of the level
+};
 
-    const int lane = threadIdx.x;
-    const int cell = xcd_remap(blockIdx.x, gridDim.x), img = blockIdx.y;
+__device__ __forceinline__ void fast_cell_setup(const uint8_t *pyr, const Geom &g, int img, int cell, FastCell &C)
+{
+    C.on = 0; C.cell = cell; C.ph = 0; C.wi = 0; C.hi = 0; C.rows = 0; C.g0 = 0; C.ng = 1; C.org = 0; C.src = pyr; C.pitch = 0;
     int level = 0;
 #pragma unroll 1
     for (int l = 1; l < g.nlevels; l++)
         if (cell >= g.lv[l].cell0) level = l;
     const LevelGeom &L = g.lv[level];
     const int cl = cell - L.cell0;
-    const int ci = cl / L.nCols, cj = cl - ci * L.nCols;
-    int *out_cnt = cell_cnt + (size_t)img * g.cells + cell;
-
+    const int ci = (int)(((float)cl + 0.5f) * __builtin_amdgcn_rcpf((float)L.nCols)), cj = cl - ci * L.nCols;
     // cell ROI exactly as the reference builds it (float there, exact in int)
     const int iniY = kMinBorder + ci * L.hCell;
     int maxY = iniY + L.hCell + 6;
@@ -254,144 +233,231 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     if (maxY > L.maxBorderY) maxY = L.maxBorderY;
     if (maxX > L.maxBorderX) maxX = L.maxBorderX;
     const int cols = maxX - iniX, rows = maxY - iniY;
-    const int wi = cols - 6, hi = rows - 6;   // FAST evaluates ROI columns 3..cols-4, rows 3..rows-4
-    if (skip || wi <= 0 || hi <= 0) {
+    C.wi = cols - 6;   // FAST evaluates ROI columns 3..cols-4, rows 3..rows-4
+    C.hi = rows - 6;
+    C.rows = rows;
+    C.ph = iniX & 3;
+    C.g0 = (C.ph + 3) >> 2;
+    C.ng = ((C.ph + 2 + C.wi) >> 2) - C.g0 + 1;
+    C.on = !(skip || C.wi <= 0 || C.hi <= 0);
+    if (!C.on) C.ng = 1;
+    C.org = ((uint32_t)(ci * L.hCell) << 20) + ((uint32_t)(cj * L.wCell - C.ph) << 8);
+    C.pitch = L.pitch;
+    C.src = pyr + (size_t)img * g.imgBytes + L.off + (size_t)iniY * L.pitch + (iniX - C.ph);
+}
+
+// Work-list capacity.  A trip of pass 1 appends at most 256 entries and runs only while 256 more still fit, so the
+// list never overflows; a cell with more survivors than that (dense texture, noise) is processed in several chunks
+// (see the kernel).  512 keeps the wave's LDS at 5 KiB = 32 waves per CU; the benchmark's cells hold 80 survivors on
+// average, 250 at most.
+constexpr int kFastListCap = 512;
+
+// pass 1 over one cell, from item `item0` (a multiple of 64) until the cell is done or the list is full; returns the
+// length of the work list and advances item0
+#define EMAX __builtin_elementwise_max
+#define EMIN __builtin_elementwise_min
+template <int TP>
+__device__ __forceinline__ int fast_pass1(const uint8_t *tile, const uint2 *cm, uint16_t *work, const FastCell &C, int T, int lane,
+                                          int &item0, int cap)
+{
+    const int ng = C.ng, items = C.hi * ng;
+    const float rng = __builtin_amdgcn_rcpf((float)ng);
+    const int q = __builtin_amdgcn_readfirstlane((int)(64.5f * rng)), rem = 64 - q * ng;   // 64 = q*ng + rem
+    // item = (row, group) in raster order, 64 consecutive items per trip: the lane's item advances by (q rows, rem groups)
+    int r = (int)(((float)(item0 + lane) + 0.5f) * rng), gi = item0 + lane - r * ng;
+    int nA = 0;
+    auto trip = [&](bool in) {
+        const int G = C.g0 + gi;
+        const int off = (int)__umul24((uint32_t)(in ? r + 3 : 3), (uint32_t)TP) + 4 * G;   // tile byte = work-list entry
+        const uint32_t *p = reinterpret_cast<const uint32_t *>(tile + off);
+        const uint2 vm = cm[in ? G : TP / 4];   // 0xffff per evaluated column of the group; entry TP/4 is all-zero
+        const uint32_t Cc = p[0], Cl = p[-1], Cr = p[1], Up = p[-3 * (TP / 4)], Dn = p[3 * (TP / 4)];
+        const uint32_t Lf = __builtin_amdgcn_alignbyte(Cc, Cl, 1);   // px 4G-3 .. 4G
+        const uint32_t Rt = __builtin_amdgcn_alignbyte(Cr, Cc, 3);   // px 4G+3 .. 4G+6
+#define LO2(X) __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, X, 0x0c010c00u))
+#define HI2(X) __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, X, 0x0c030c02u))
+        const s16x2 V0 = LO2(Cc), V1 = HI2(Cc), U0 = LO2(Up), U1 = HI2(Up), D0 = LO2(Dn), D1 = HI2(Dn);
+        const s16x2 L0 = LO2(Lf), L1 = HI2(Lf), R0 = LO2(Rt), R1 = HI2(Rt);
+#undef LO2
+#undef HI2
+        const s16x2 w0 = EMAX(EMIN(EMAX(U0, D0), EMAX(L0, R0)) - V0, V0 - EMAX(EMIN(U0, D0), EMIN(L0, R0)));
+        const s16x2 w1 = EMAX(EMIN(EMAX(U1, D1), EMAX(L1, R1)) - V1, V1 - EMAX(EMIN(U1, D1), EMIN(L1, R1)));
+        const s16x2 m0 = __builtin_bit_cast(s16x2, __builtin_bit_cast(uint32_t, w0) & vm.x);
+        const s16x2 m1 = __builtin_bit_cast(s16x2, __builtin_bit_cast(uint32_t, w1) & vm.y);
+        const bool c0 = m0.x > T, c1 = m0.y > T, c2 = m1.x > T, c3 = m1.y > T;   // T >= 0: masked-out columns never pass
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(c0), b1 = __builtin_amdgcn_ballot_w64(c1),
+                                 b2 = __builtin_amdgcn_ballot_w64(c2), b3 = __builtin_amdgcn_ballot_w64(c3);
+        int o = lane_rank(b3, lane_rank(b2, lane_rank(b1, lane_rank(b0, nA))));
+        if (c0) work[o++] = (uint16_t)off;
+        if (c1) work[o++] = (uint16_t)(off + 1);
+        if (c2) work[o++] = (uint16_t)(off + 2);
+        if (c3) work[o++] = (uint16_t)(off + 3);
+        nA += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+    };
+    int i0 = item0;
+    for (; i0 + 64 <= items && nA + 256 <= cap; i0 += 64) {   // full trips: every lane holds an item
+        trip(true);
+        gi += rem; r += q;
+        if (gi >= ng) { gi -= ng; r += 1; }
+    }
+    if (i0 < items && i0 + 64 > items && nA + 256 <= cap) {   // last trip: lanes past the end take the all-zero mask entry
+        trip(i0 + lane < items);   // (a select, not a branch: the ballots inside need the whole wave)
+        i0 += 64;
+    }
+    item0 = i0;
+    return nA;
+}
+
+// arc score of the pixel at byte c of the u8 LDS tile (pitch TP): A as defined above, 0 <= A <= 255.
+// (Fetching the ring with seven unaligned ds_read_b32/b64 per pixel instead of 17 byte reads is functionally fine on
+// gfx950 but was measured 2x slower for the whole kernel: 900 vs 435 us per 128 images.)
+template <int TP>
+__device__ __forceinline__ int fast_arc_score(const uint8_t *lo)   // lo = &pixel[-3 rows][-3 columns]: all offsets >= 0
+{
+    const uint8_t *c = lo + 3 * TP + 3;
+    // ring offsets (dx,dy), k = 0..15 (cv::FAST makeOffsets, patternSize 16): (0,3),(1,3),(2,2),(3,1),(3,0),(3,-1),(2,-2),(1,-3),
+    // then the same negated for k+8.  X[k] = (r[k], r[k+8]) as two u16
+    u16x2 X[8];
+    X[0] = u16x2{c[3 * TP], c[-3 * TP]};          X[1] = u16x2{c[3 * TP + 1], c[-3 * TP - 1]};
+    X[2] = u16x2{c[2 * TP + 2], c[-2 * TP - 2]};  X[3] = u16x2{c[TP + 3], c[-TP - 3]};
+    X[4] = u16x2{c[3], c[-3]};                    X[5] = u16x2{c[-TP + 3], c[TP - 3]};
+    X[6] = u16x2{c[-2 * TP + 2], c[2 * TP - 2]};  X[7] = u16x2{c[-3 * TP + 1], c[3 * TP - 1]};
+    const uint32_t v = c[0];
+    // suffix / prefix scans of both 8-blocks at once (block 0 in the low halves, block 1 in the high halves)
+    u16x2 Sn[8], Sx[8], Pn[8], Px[8];
+    Sn[7] = Sx[7] = X[7];
+    Pn[0] = Px[0] = X[0];
+#pragma unroll
+    for (int i = 6; i >= 1; i--) { Sn[i] = EMIN(X[i], Sn[i + 1]); Sx[i] = EMAX(X[i], Sx[i + 1]); }
+#pragma unroll
+    for (int i = 1; i < 8; i++) { Pn[i] = EMIN(X[i], Pn[i - 1]); Px[i] = EMAX(X[i], Px[i - 1]); }
+    Sn[0] = Pn[7]; Sx[0] = Px[7];   // whole-block minimum / maximum
+    // nine-window starting at k (low half) and at k+8 (high half) = suffix k of its own block + prefix k of the other block
+    u16x2 bn, bx;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const u16x2 wn = EMIN(Sn[k], __builtin_shufflevector(Pn[k], Pn[k], 1, 0));   // min over the window: bright arcs
+        const u16x2 wx = EMAX(Sx[k], __builtin_shufflevector(Px[k], Px[k], 1, 0));   // max over the window: dark arcs
+        bn = k ? EMAX(bn, wn) : wn;
+        bx = k ? EMIN(bx, wx) : wx;
+    }
+    const int Mx = max((int)bn.x, (int)bn.y), Mn = min((int)bx.x, (int)bx.y);
+    const int a = max(Mx - (int)v, (int)v - Mn);
+    return a < 0 ? 0 : a;
+}
+#undef EMAX
+#undef EMIN
+
+// TP: LDS row pitch in bytes of every cell of the launch (48 fits all 35-px cells of the usual resolutions), a
+// compile-time constant so that the ring / neighbour offsets fold into the ds_read offset fields.
+// One wave per cell.  (Several cells per wave, one after the other with the next ROI prefetched into registers, or two
+// cells with pooled survivor lists, were measured slower: the extra LDS / SGPRs cost more occupancy than they save --
+// 443-456 us and 787 us against 431 us per 128 images.)
+// LDS of the wave: [16 B][tile, tileB][16 B][score map of ROI rows 2 .. rows-3, scB][16 B][column masks, (TP/4 + 1) x 8 B]
+// [work list, cap x 2 B] = 5 KiB at TP = 48: 32 waves per CU; <= 80 SGPRs and <= 64 VGPRs keep 8 waves per SIMD.
+template <int TP>
+__global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom g, int iniTh, int minTh,
+                                                   int tileB, int scB, int cap, uint32_t *__restrict__ cell_kp,
+                                                   int *__restrict__ cell_cnt)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    constexpr int NQ = TP / 16, NG = TP / 4;
+    uint8_t *tile = lds + 16;
+    uint8_t *sc = tile + tileB + 16;          // score of tile byte `pos` lives at sc2[pos]: NMS touches rows 2 .. rows-3 only
+    uint8_t *sc2 = sc - 2 * TP;
+    uint2 *cm = reinterpret_cast<uint2 *>(sc + scB + 16);
+    uint16_t *work = reinterpret_cast<uint16_t *>(cm + (NG + 1));
+    struct __attribute__((packed, aligned(4))) Chunk { uint32_t a, b, c, d; };
+
+    const int lane = threadIdx.x;
+    const int img = blockIdx.y;
+    FastCell C;
+    fast_cell_setup(pyr, g, img, __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x)), C);
+    int *out_cnt = cell_cnt + (size_t)img * g.cells + C.cell;
+    if (!C.on) {
         if (lane == 0) *out_cnt = 0;
         return;
     }
 
-    // ---- stage the ROI in LDS, same byte phase as HBM: 16-byte chunks (4-byte aligned in HBM, 16-byte
-    //      aligned in LDS), two per lane per trip with both loads issued before the first store so that a
-    //      35-px cell costs one HBM round trip instead of eight ----
-    const uint8_t *plane = pyr + (size_t)img * g.imgBytes + L.off;
-    const int ph = iniX & 3;
-    const int nq = TPC ? TPC / 16 : (ph + cols + 15) >> 4;   // 16-byte chunks per row, <= 3 for 35-px cells
-    const int nd = nq * 4;                  // dwords per LDS row
-    const int TP = nq * 16;                 // LDS pitch of this cell
+    // ---- stage the ROI: row = lane, NQ 16-byte chunks per row (4-byte aligned in HBM, 16-byte aligned in LDS), all
+    //      loads issued before the first LDS store; clear the score map, build the column masks ----
+    for (int r = lane; r < C.rows; r += 64) {   // one trip unless the ROI is taller than 64 rows (70-px cells of odd resolutions)
+        Chunk ch[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) ch[q] = *reinterpret_cast<const Chunk *>(C.src + (size_t)r * C.pitch + 16 * q);
+        uint4 *dst = reinterpret_cast<uint4 *>(tile + r * TP);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) dst[q] = uint4{ch[q].a, ch[q].b, ch[q].c, ch[q].d};
+    }
     {
-        struct __attribute__((packed, aligned(4))) Chunk { uint32_t a, b, c, d; };
-        const uint8_t *src0 = plane + (size_t)iniY * L.pitch + (iniX - ph);
-        uint4 *t128 = reinterpret_cast<uint4 *>(tile);
         uint4 *s128 = reinterpret_cast<uint4 *>(sc);
-        const int ntask = rows * nq;
-        const float rcp_nq = 1.0f / (float)nq;
-        for (int i0 = 0; i0 < ntask; i0 += 128) {
-            const int ia = i0 + lane, ib = i0 + 64 + lane;
-            const int ya = (int)(((float)ia + 0.5f) * rcp_nq), yb = (int)(((float)ib + 0.5f) * rcp_nq);
-            Chunk ca = {0, 0, 0, 0}, cb = {0, 0, 0, 0};
-            if (ia < ntask) ca = *reinterpret_cast<const Chunk *>(src0 + (size_t)ya * L.pitch + 16 * (ia - ya * nq));
-            if (ib < ntask) cb = *reinterpret_cast<const Chunk *>(src0 + (size_t)yb * L.pitch + 16 * (ib - yb * nq));
-            if (ia < ntask) { t128[ia] = uint4{ca.a, ca.b, ca.c, ca.d}; s128[ia] = uint4{0, 0, 0, 0}; }
-            if (ib < ntask) { t128[ib] = uint4{cb.a, cb.b, cb.c, cb.d}; s128[ib] = uint4{0, 0, 0, 0}; }
+        for (int i = lane; i < scB / 16; i += 64) s128[i] = uint4{0, 0, 0, 0};
+        if (lane <= NG) {   // evaluated tile columns of this cell: [ph + 3, ph + 3 + wi); entry NG stays all-zero
+            const int x = 4 * lane - (C.ph + 3);
+            const uint32_t a0 = (unsigned)x < (unsigned)C.wi ? 0xffffu : 0u, a1 = (unsigned)(x + 1) < (unsigned)C.wi ? 0xffff0000u : 0u;
+            const uint32_t a2 = (unsigned)(x + 2) < (unsigned)C.wi ? 0xffffu : 0u, a3 = (unsigned)(x + 3) < (unsigned)C.wi ? 0xffff0000u : 0u;
+            cm[lane] = lane < NG ? uint2{a0 | a1, a2 | a3} : uint2{0, 0};
         }
     }
     __syncthreads();   // single-wave workgroup: lowers to a wait, not an s_barrier
 
-    const float rcp_tp = 1.0f / (float)TP;
-    uint32_t *dst = cell_kp + ((size_t)img * g.cells + cell) * g.cellCap;
+    uint32_t *dst = cell_kp + ((size_t)img * g.cells + C.cell) * g.cellCap;
+    const int items = C.hi * C.ng;
     int total = 0;
-
+    // pass 2: full arc score of the survivors; the score map gets A where A > T, 0 elsewhere
+    auto score = [&](int nA, int T) {
+        for (int i = lane; i < nA; i += 64) {
+            const int pos = work[i];
+            const int a = fast_arc_score<TP>(tile + (pos - 3 * TP - 3));
+            sc2[pos] = (uint8_t)(a > T ? a : 0);
+        }
+    };
+    // pass 3: NMS over the work list; it is in raster order, so keypoints are emitted in cv::FAST's order.
+    // keep <=> score strictly above the 8 neighbours' (0 where not a corner)
+    auto nms = [&](int nA) {
+        for (int i0 = 0; i0 < nA; i0 += 64) {
+            const int i = i0 + lane;
+            const int pos = work[i < nA ? i : nA - 1];
+            const uint8_t *s = sc2 + pos;
+            const uint32_t a = s[0];
+            const uint32_t n = max(max(max((uint32_t)s[1], (uint32_t)s[-1]), max((uint32_t)s[-TP - 1], (uint32_t)s[-TP])),
+                                   max(max((uint32_t)s[-TP + 1], (uint32_t)s[TP - 1]), max((uint32_t)s[TP], (uint32_t)s[TP + 1])));
+            const bool keep = i < nA && a > n;
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
+            if (keep) {
+                const int o = lane_rank(b, total);
+                const int yy = (int)(((float)pos + 0.5f) * (1.0f / (float)TP)), xx = pos - yy * TP;   // tile coordinates
+                // keypoint coordinates relative to minBorder: FAST's ROI coordinate + cell origin (:864-865)
+                if (o < g.cellCap) dst[o] = C.org + ((uint32_t)yy << 20) + ((uint32_t)xx << 8) + (a - 1);
+            }
+            total += __popcll(b);
+        }
+    };
     // The reference calls cv::FAST at iniTh and, only when the cell came out empty, again at minTh
-    // (ORBextractor.cpp:847-856).  Same here: everything below runs at T = iniTh first (NMS only ever
-    // looks at scores above T, so pixels failing the tests at T need no score), and the wave-uniform
-    // retry at minTh is paid by empty cells only.
+    // (ORBextractor.cpp:847-856).  Same here: the wave-uniform retry is paid by empty cells only.
     int T = iniTh;
 #pragma unroll 1
     for (int attempt = 0; attempt < 2; attempt++) {
-    // ---- pass 1: 4-point test, 4 horizontally adjacent pixels per lane: five aligned LDS dwords
-    //      (centre, left, right, 3 rows up, 3 rows down) feed packed 16-bit min/max; survivors are
-    //      appended in raster order (lanes run row-major over the trip's rows, then byte position) ----
-    int nA = 0;
-    {
-        const uint32_t *t32 = reinterpret_cast<const uint32_t *>(tile);
-        const int g0 = (ph + 3) >> 2, g1 = (ph + 2 + wi) >> 2, ng = g1 - g0 + 1;   // 4-px groups per row, <= 19
-        const int cmin = ph + 3, cmax = ph + 3 + wi;   // valid tile columns [cmin, cmax)
-        const s16x2 zero = {0, 0};
-        // lane = (row within the trip) * ng + group: the column part of every address and the column validity are
-        // per-lane constants, a trip only advances the row (64 / ng rows per trip; lanes beyond that idle)
-        const int rpi = (int)(64.0f / (float)ng + 0.01f);
-        const int lr = (int)(((float)lane + 0.5f) / (float)ng), gq = g0 + (lane - lr * ng);
-        const bool lane_on = lr < rpi;
-        const int col = 4 * gq;   // only the first / last group of a row can hold columns outside [cmin, cmax)
-        const bool v0 = lane_on && col >= cmin && col < cmax, v1 = lane_on && col + 1 >= cmin && col + 1 < cmax;
-        const bool v2 = lane_on && col + 2 >= cmin && col + 2 < cmax, v3 = lane_on && col + 3 >= cmin && col + 3 < cmax;
-        for (int r0 = 0; r0 < hi; r0 += rpi) {
-            const int rq = r0 + lr;
-            const bool in = rq < hi;
-            const int r = in ? rq : hi - 1;   // rows past the end redo the last one; their results are masked out
-            const int di = (r + 3) * nd + gq;
-            const uint32_t C = t32[di], Cl = t32[di - 1], Cr = t32[di + 1], U = t32[di - 3 * nd], Dn = t32[di + 3 * nd];
-            const uint32_t Lf = __builtin_amdgcn_alignbyte(C, Cl, 1);   // columns 4g-3 .. 4g
-            const uint32_t Rt = __builtin_amdgcn_alignbyte(Cr, C, 3);   // columns 4g+3 .. 4g+6
-            const int pos = (r + 3) * TP + 4 * gq;
-            s16x2 mm[2];
-#pragma unroll
-            for (int hgh = 0; hgh < 2; hgh++) {
-                const uint32_t sel = hgh ? 0x0c030c02u : 0x0c010c00u;
-#define UNP(X) __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, X, sel))
-                const s16x2 V = UNP(C);
-                const s16x2 d0 = V - UNP(Dn), d4 = V - UNP(Rt), d8 = V - UNP(U), d12 = V - UNP(Lf);
-#undef UNP
-                const s16x2 lo = __builtin_elementwise_max(
-                    __builtin_elementwise_max(__builtin_elementwise_min(d0, d4), __builtin_elementwise_min(d4, d8)),
-                    __builtin_elementwise_max(__builtin_elementwise_min(d8, d12), __builtin_elementwise_min(d12, d0)));
-                const s16x2 hi2 = __builtin_elementwise_min(
-                    __builtin_elementwise_min(__builtin_elementwise_max(d0, d4), __builtin_elementwise_max(d4, d8)),
-                    __builtin_elementwise_min(__builtin_elementwise_max(d8, d12), __builtin_elementwise_max(d12, d0)));
-                mm[hgh] = __builtin_elementwise_max(lo, zero - hi2);
+        // sweep 0 scores the survivors, chunk by chunk when the list cannot hold them all; the usual cell fits in
+        // one chunk and is finished right away.  Otherwise sweep 1 goes over the cell again for the NMS (the
+        // score map is complete by then).
+        int item0 = 0, sweep = 0;
+#pragma unroll 1
+        for (;;) {
+            const bool whole = item0 == 0;
+            const int nA = fast_pass1<TP>(tile, cm, work, C, T, lane, item0, cap);
+            __syncthreads();
+            if (sweep == 0) {
+                score(nA, T);
+                __syncthreads();
             }
-            const bool c0 = in && v0 && mm[0].x > T;
-            const bool c1 = in && v1 && mm[0].y > T;
-            const bool c2 = in && v2 && mm[1].x > T;
-            const bool c3 = in && v3 && mm[1].y > T;
-            const unsigned long long b0 = __ballot(c0), b1 = __ballot(c1), b2 = __ballot(c2), b3 = __ballot(c3);
-            int o = lane_rank(b3, lane_rank(b2, lane_rank(b1, lane_rank(b0, nA))));
-            if (c0) work[o++] = (uint16_t)pos;
-            if (c1) work[o++] = (uint16_t)(pos + 1);
-            if (c2) work[o++] = (uint16_t)(pos + 2);
-            if (c3) work[o++] = (uint16_t)(pos + 3);
-            nA += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
-        }
-    }
-    __syncthreads();
-
-    // (An 8-point test between the two passes was measured and dropped: at iniTh it removes only ~16 % of the survivors of
-    // the 4-point test, less than its own cost; the survivors go straight to the full score.)
-    const int nB = nA;
-
-    // ---- pass 2: full arc score of the survivors ----
-    for (int i = lane; i < nB; i += 64) {
-        const int pos = work[i];
-        sc[pos] = (uint8_t)fast_arc_max(tile + pos, TP);
-    }
-    __syncthreads();
-
-    // ---- pass 3: NMS over the work list; it is in raster order, so keypoints are emitted in cv::FAST's order ----
-        for (int i0 = 0; i0 < nB; i0 += 64) {
-            const int i = i0 + lane;
-            bool keep = false;
-            int pos = 0, a = 0;
-            if (i < nB) {
-                pos = work[i];
-                const uint8_t *s = sc + pos;
-                a = s[0];
-                if (a > T) {
-                    const int e = a - 1;   // cornerScore
-#define EFF(q) ((int)(q) > T ? (int)(q)-1 : 0)
-                    const int n0 = max(max(EFF(s[1]), EFF(s[-1])), max(EFF(s[-TP - 1]), EFF(s[-TP])));
-                    const int n1 = max(max(EFF(s[-TP + 1]), EFF(s[TP - 1])), max(EFF(s[TP]), EFF(s[TP + 1])));
-#undef EFF
-                    keep = e > max(n0, n1);
-                }
+            if (sweep == 1 || (whole && item0 >= items)) nms(nA);
+            if (item0 >= items) {
+                if (sweep == 1 || whole) break;
+                sweep = 1;
+                item0 = 0;
             }
-            const unsigned long long b = __ballot(keep);
-            if (keep) {
-                const int o = lane_rank(b, total);
-                const int yy = (int)(((float)pos + 0.5f) * rcp_tp), xx = pos - yy * TP - ph;   // ROI coordinates
-                // keypoint coordinates relative to minBorder: FAST's ROI coordinate + cell origin (:864-865)
-                if (o < g.cellCap) dst[o] = pack_cand(xx + cj * L.wCell, yy + ci * L.hCell, a - 1);
-            }
-            total += __popcll(b);
+            __syncthreads();
         }
         if (total || T == minTh) break;
         T = minTh;
@@ -573,8 +639,6 @@ __global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ c
 // packed u16 (every partial sum <= 65280, so v_pk_* arithmetic is exact), vertical
 // pass in 32 bits, dword stores.
 // ---------------------------------------------------------------------------
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ uint32_t load4_reflect(const uint8_t *plane, int pitch, int w, int sy, int x)
 {
     const uint8_t *row = plane + (size_t)sy * pitch;
@@ -1106,22 +1170,25 @@ void launch_pyramid(hipStream_t st, uint8_t *pyr, const Geom &g, const ResizeTap
 void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, uint32_t *cell_kp,
                  int *cell_cnt, int nimg)
 {
-    dim3 grid(g.cells, nimg);
-    // LDS per cell: ROI rows x 16-byte-aligned pitch (3 phase bytes + wCell + 6), for the tile and for the score map
+    // LDS per wave: ROI rows x pitch (3 phase bytes + wCell + 6, rounded up to whole 16-byte chunks) for the tile, four
+    // rows fewer for the score map, the bounded survivor list
     int pitch = 0, rows = 0;
     for (int l = 0; l < g.nlevels; l++) {
         const int p = ((3 + g.lv[l].wCell + 6 + 15) >> 4) << 4;
         pitch = pitch > p ? pitch : p;
         rows = rows > g.lv[l].hCell + 6 ? rows : g.lv[l].hCell + 6;
     }
-    const int tpc = pitch <= 48 ? 48 : (pitch <= 64 ? 64 : 0);   // one fixed pitch for the whole launch when it fits
-    const int tileBytes = (rows * (tpc ? tpc : pitch) + 15) & ~15;
-    int maxNi = 0;   // interior pixels of a cell = worst-case length of the survivor list (u16 entries)
-    for (int l = 0; l < g.nlevels; l++) maxNi = maxNi > g.lv[l].wCell * g.lv[l].hCell ? maxNi : g.lv[l].wCell * g.lv[l].hCell;
-    const size_t lds = 2 * tileBytes + ((2 * maxNi + 15) & ~15);
-    if (tpc == 48) hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileBytes, cell_kp, cell_cnt);
-    else if (tpc == 64) hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileBytes, cell_kp, cell_cnt);
-    else hipLaunchKernelGGL(k_fast_cells<0>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileBytes, cell_kp, cell_cnt);
+    const int tp = pitch <= 48 ? 48 : (pitch <= 64 ? 64 : 80);   // wCell < 70 by construction (build_geometry): pitch <= 80
+    const int tileB = (rows * tp + 15) & ~15, scB = ((rows - 4) * tp + 15) & ~15;
+    static const int cap_env = getenv("MCORB_FAST_LISTCAP") ? atoi(getenv("MCORB_FAST_LISTCAP")) : 0;   // tuning knob; any value >= 512 is safe
+    const int cap = cap_env >= 512 ? cap_env : kFastListCap;
+    const size_t lds = 16 + (size_t)tileB + 16 + (size_t)scB + 16 + (size_t)(tp / 4 + 1) * 8 + (size_t)cap * 2;
+    dim3 grid(g.cells, nimg);
+    if (iniTh < 0) iniTh = 0;   // (the kernel's column masks rely on thresholds >= 0; FAST thresholds are)
+    if (minTh < 0) minTh = 0;
+    if (tp == 48) hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, cell_kp, cell_cnt);
+    else if (tp == 64) hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, cell_kp, cell_cnt);
+    else hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, cell_kp, cell_cnt);
 }
 
 void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt, const Geom &g, uint32_t *sorted_dev,

@@ -73,6 +73,41 @@ def test_image_content(mc, kind):
         assert len(ref[1]) >= 1000
 
 
+def _four_point_survivors_per_cell(img, T):
+    """Survivors of k_fast_cells' pass-1 test (two neighbouring compass points beyond the threshold) per 35-px cell of
+    level 0 -- numpy restatement, used to make sure an image really drives the kernel's chunked work-list path."""
+    v = img.astype(np.int32)
+
+    def sh(dx, dy):
+        return np.roll(np.roll(v, -dy, 0), -dx, 1)
+    U, D, L, R = sh(0, -3), sh(0, 3), sh(-3, 0), sh(3, 0)
+    w = np.maximum(np.minimum(np.maximum(U, D), np.maximum(L, R)) - v, v - np.maximum(np.minimum(U, D), np.minimum(L, R)))
+    H, W = img.shape
+    x1, y1 = W - 16, H - 16
+    nC, nR = (x1 - 16) // 35, (y1 - 16) // 35
+    wC, hC = -(-(x1 - 16) // nC), -(-(y1 - 16) // nR)
+    out = []
+    for i in range(nR):
+        for j in range(nC):
+            ya, xa = 16 + i * hC + 3, 16 + j * wC + 3
+            out.append(int((w[ya:min(ya + hC, y1 - 3), xa:min(xa + wC, x1 - 3)] > T).sum()))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("ini,mn", [(20, 7), (5, 5), (60, 3)])
+def test_fast_worklist_chunking(mc, ini, mn):
+    """Cells with more pass-1 survivors than k_fast_cells' work list holds (kFastListCap = 512): the kernel scores them
+    chunk by chunk and sweeps the cell a second time for the NMS.  Pure noise gives 500-1300 survivors per cell."""
+    img = _content("noise", 640, 480)
+    assert (_four_point_survivors_per_cell(img, ini) > 600).any() or (_four_point_survivors_per_cell(img, mn) > 600).any()
+    same(O.OracleExtractor(1500, 1.2, 8, ini, mn)(img), mc.ORBextractor(1500, 1.2, 8, ini, mn)(img), "noise %d/%d" % (ini, mn))
+    # half noise, half flat: chunked and ordinary cells side by side, empty cells retried at minTh
+    img2 = img.copy()
+    img2[:, 320:] = 90
+    img2[200:260, 400:500] = _content("noise", 100, 60)
+    same(O.OracleExtractor(1500, 1.2, 8, ini, mn)(img2), mc.ORBextractor(1500, 1.2, 8, ini, mn)(img2), "half noise %d/%d" % (ini, mn))
+
+
 @pytest.mark.parametrize("C", [5, 8])
 def test_rigs_wider_than_the_reference_track_type(mc, C):
     W, H, N = 480, 360, 400
