@@ -1,23 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- multi-camera ORB front-end throughput on MI355X.
 
-Workload (BASELINE.json configs[1]): 4-camera rig, 1280x720, 2000 keypoints/camera,
-extract + all-pairs intra-rig match.  One *step* = one batch of F synthetic rig
-frames per rank through the whole hot path (pyramid -> FAST -> selection -> blur ->
-BRIEF -> k-NN(k=2) + ratio filter -> track merge), inputs resident in HBM before the
-timed region.  `value` = rig frames / second over all ranks.
+Workload (`--config`, default 720p4 = BASELINE.json configs[1]): 4-camera rig, 1280x720, 2000 keypoints/camera,
+extract + all-pairs intra-rig match; 1080p8 = configs[2]: 8 cameras, 1920x1080 (one camera per GPU at --gpus 8).
+One *step* = one batch of F synthetic rig frames per rank through the whole hot path (pyramid -> FAST -> selection ->
+blur -> BRIEF -> k-NN(k=2) + ratio filter -> track merge), inputs resident in HBM before the timed region.
+`value` = rig frames / second over all ranks: the median of `--repeats` timed regions of exactly `--steps` steps each
+(`value_min` / `value_max` give the spread).
 
-N = 1: cameras and pairs all on one GPU, S slots in flight (the host selection stage
-of one sub-batch overlaps the GPU phases of the others).
-N > 1 (weak scaling, F frames per rank per step, F*N frames per step in total):
-camera c of frame f is extracted on rank (c + f) mod N; per-camera descriptors are
-exchanged with ONE RCCL all-gather per step; frame f is matched on rank f mod N.
+N = 1: cameras and pairs all on one GPU, S slots in flight (the host selection stage of one sub-batch overlaps the GPU
+phases of the others).
+N > 1 (weak scaling, F frames per rank per step, F*N frames per step in total): camera c of frame f is extracted on
+rank (c + f) mod N; every descriptor set travels to the rank that matches its frame (f mod N) with ONE RCCL all-to-all
+per step (uneven splits, mc-slam_amd/sharding.py) -- stream-ordered: export -> collective -> match without a host sync.
 
-Extra legs on rank 0 at N = 1: `cpu_baseline` (the CPU oracle, one thread per camera
-as the reference's extractFeaturesParallel does, on a bounded sample) and a bit-exact
-GPU-vs-oracle check of the first frame.
+Extra legs on rank 0 at N = 1 (none of them part of `value`):
+  value_with_staging / value_with_upload_u8 / pcie_gbs   the same steps with the PCIe hand-off in front of every batch
+  cpu_baseline                                           the CPU oracle on a bounded sample, every frame checked bit-exact
+  single_frame_latency_ms                                one rig frame at a time, nothing in flight
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,16 +34,21 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 
 import numpy as np  # noqa: E402
 
-W, H, NCAMS, NFEAT = 1280, 720, 4, 2000
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+CONFIGS = {
+    "720p4": dict(W=1280, H=720, NCAMS=4, NFEAT=2000,
+                  label="4-cam rig 1280x720, 2000 kpts/cam, extract + all-pairs intra-rig match (configs[1])"),
+    "1080p8": dict(W=1920, H=1080, NCAMS=8, NFEAT=2000,
+                   label="8-cam rig 1920x1080, 2000 kpts/cam, extract + all-pairs intra-rig match (configs[2])"),
+}
+IMAGES_PER_LAUNCH = 128     # camera images per slot job (32 four-camera or 16 eight-camera rig frames)
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
+GPU_KERNELS = ("k_resize", "k_fast_cells", "k_compact", "k_blur", "k_describe", "k_knn2")
+TIMING_FIELD = {"k_resize": "pyramid_us", "k_fast_cells": "fast_us", "k_compact": "compact_us", "k_blur": "blur_us",
+                "k_describe": "describe_us", "k_knn2": "knn2_us", "select_host": "select_us"}
 
 
-def level_pixels(rig):
-    return [rig.level_size(l) for l in range(rig.nlevels)]
-
-
-def algorithmic_bytes(kernel, S, S0, s_last, K, Kc, npairs_per_frame=6):
-    """Per camera image (or per frame for knn2), SURVEY.md 8(d) with this build's record sizes."""
+def algorithmic_bytes(kernel, S, S0, s_last, K, Kc, buckets):
+    """Per camera image (per camera pair for k_knn2), SURVEY.md 8(d) with this build's record sizes."""
     if kernel == "k_fast_cells":      # read every level once + packed 4-byte candidate records out
         return S + 4 * Kc
     if kernel == "k_resize":          # read levels 0..n-2, write levels 1..n-1
@@ -51,34 +59,45 @@ def algorithmic_bytes(kernel, S, S0, s_last, K, Kc, npairs_per_frame=6):
         return K * (512 + 32)
     if kernel == "k_knn2":            # per pair: both descriptor sets once + 8-byte partial per query
         return 2 * K * 32 + K * 16
+    if kernel == "k_compact":         # candidates in, sorted candidates out, bucket starts + per-bucket winners out
+        return 2 * 4 * Kc + 16 * buckets
     raise KeyError(kernel)
 
 
-def cpu_baseline(frames, ncams):
+def cpu_baseline(cfg, frames, threads):
     """Oracle timed the way the reference runs: one thread per camera for extraction
-    (MultiCameraFrame.cpp:212-227), matching + track merge on the calling thread."""
+    (MultiCameraFrame.cpp:212-227), matching + track merge on the calling thread; threads=1: everything on one thread."""
     import mcorb
     import oracle_lib as O
-    exs = [O.OracleExtractor(NFEAT) for _ in range(ncams)]
+    W, H, C, NFEAT = cfg["W"], cfg["H"], cfg["NCAMS"], cfg["NFEAT"]
+    exs = [O.OracleExtractor(NFEAT) for _ in range(C)]
     times, t_extract, results = [], [], []
     for f in frames:
-        imgs = [mcorb.synth_rig_frame(f, ncams, c, W, H) for c in range(ncams)]
-        res = [None] * ncams
+        imgs = [mcorb.synth_rig_frame(f, C, c, W, H) for c in range(C)]
+        res = [None] * C
         t0 = time.perf_counter()
 
         def work(c):
             res[c] = exs[c](imgs[c])
-        ths = [threading.Thread(target=work, args=(c,)) for c in range(ncams)]
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
+        if threads == 1:
+            for c in range(C):
+                work(c)
+        else:
+            ths = [threading.Thread(target=work, args=(c,)) for c in range(C)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
         t1 = time.perf_counter()
         tracks, _ = O.intra_matches([r[2] for r in res])
         times.append(time.perf_counter() - t0)
         t_extract.append(t1 - t0)
         results.append((res, tracks))
-    return times, t_extract, results
+    return np.array(times), np.array(t_extract), results
+
+
+def kernels_sha():
+    return hashlib.sha256(open(os.path.join(ROOT, "mc-slam_amd", "csrc", "mcorb_kernels.hip"), "rb").read()).hexdigest()[:16]
 
 
 def main():
@@ -86,16 +105,23 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=None, help="rig frames per rank per step (default 192; 128 on the N>1 path)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="720p4")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; value = their median")
+    ap.add_argument("--frames", type=int, default=None, help="rig frames per rank per step (default: slots x 128 images / cameras)")
     ap.add_argument("--slots", type=int, default=None, help="buffer sets in flight per rank (default 6; 8 = 4 groups x 2 on the N>1 path)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-frames", type=int, default=48, help="rig frames timed on the CPU oracle (about 12 s of CPU work on 4 threads)")
+    ap.add_argument("--cpu-frames", type=int, default=64, help="rig frames timed on the CPU oracle (one thread per camera)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (use when profiling kernels)")
+    ap.add_argument("--no-staging", action="store_true", help="skip the PCIe-inclusive legs")
+    ap.add_argument("--iso-jobs", type=int, default=12, help="jobs run alone on the GPU for the isolated kernel durations")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL); 'gloo' only to rehearse N>1 on a 1-GPU box")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses device 0")
     ap.add_argument("--force-dist", action="store_true",
-                    help="rehearsal: take the N>1 code path (export -> RCCL all-gather -> external match) even at N=1")
+                    help="rehearsal: take the N>1 code path (export -> RCCL all-to-all -> external match) even at N=1")
+    ap.add_argument("--dump-tracks", default=None, help="(tests) write the tracks of this rank's first frames to an .npz")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    W, H, NCAMS, NFEAT = cfg["W"], cfg["H"], cfg["NCAMS"], cfg["NFEAT"]
 
     import torch
     import mcorb
@@ -111,7 +137,7 @@ def main():
     torch.cuda.set_device(local)
     dist = None
     gloo = args.dist_backend == "gloo"
-    DIST = N > 1 or args.force_dist     # use the sharded path (export -> all-gather -> external match)
+    DIST = N > 1 or args.force_dist     # use the sharded path (export -> all-to-all -> external match)
     if DIST:
         import torch.distributed as dist
         if args.force_dist and "RANK" not in os.environ:
@@ -134,13 +160,13 @@ def main():
                 os.dup2(saved, 1)
                 os.close(saved)
 
-    F = args.frames if args.frames else (128 if DIST else 192)   # N = 1: 6 slots x 32 rig frames = 128 images per launch
     S = args.slots if args.slots else (8 if DIST else 6)
-    S = max(1, min(S, F))
     G = int(os.environ.get("MCORB_BENCH_GROUPS", "4")) if DIST else 1   # slot groups: with N > 1 G-1 groups extract steps k+1.. while one matches step k
     if DIST and S % G:
         S += G - S % G
     SG = S // G                        # slots per group
+    F = args.frames if args.frames else SG * max(1, IMAGES_PER_LAUNCH // NCAMS)
+    S = max(1, min(S, F)) if not DIST else S
     fps = F // SG                      # rig frames per slot job
     if fps * SG != F:
         raise SystemExit("--frames must be a multiple of the slots per group (%d)" % SG)
@@ -158,48 +184,61 @@ def main():
     if not DIST:
         mine = [(f, c) for f in range(F) for c in range(NCAMS)]
     else:
-        mine = shard.images_of_rank(rank, N, NCAMS, total_frames)
+        mine = shard.a2a_images_of_rank(rank, N, NCAMS, total_frames)
     assert len(mine) == F * NCAMS, (len(mine), F * NCAMS)
     per_slot = fps * NCAMS
+    slot_imgs = []
     for s in range(S):
         i = s % SG
         imgs = [mcorb.synth_rig_frame(f, NCAMS, c, W, H) for (f, c) in mine[i * per_slot:(i + 1) * per_slot]]
         rig.upload(imgs, slot=s)
+        slot_imgs.append(imgs)
 
     if DIST:
-        local_desc = [torch.zeros((F * NCAMS, kcap, 32), dtype=torch.uint8, device="cuda") for _ in range(G)]
-        all_desc = [torch.zeros((N * F * NCAMS, kcap, 32), dtype=torch.uint8, device="cuda") for _ in range(G)]
-        local_cnt = [torch.zeros(F * NCAMS, dtype=torch.int32, device="cuda") for _ in range(G)]
-        all_cnt = [torch.zeros(N * F * NCAMS, dtype=torch.int32, device="cuda") for _ in range(G)]
-        my_frames, sets = shard.match_sets(rank, N, NCAMS, total_frames)   # gathered set index of (f, c)
+        nsets = F * NCAMS                                       # sets a rank exports = sets it receives, per step
+        send_splits = shard.a2a_send_splits(rank, N, NCAMS, total_frames)
+        recv_splits = shard.a2a_recv_splits(rank, N, NCAMS, total_frames)
+        assert sum(send_splits) == nsets and sum(recv_splits) == nsets
+        local_desc = [torch.zeros((nsets, kcap, 32), dtype=torch.uint8, device="cuda") for _ in range(G)]
+        recv_desc = [torch.zeros((nsets, kcap, 32), dtype=torch.uint8, device="cuda") for _ in range(G)]
+        local_cnt = [torch.zeros(nsets, dtype=torch.int32, device="cuda") for _ in range(G)]
+        recv_cnt = [torch.zeros(nsets, dtype=torch.int32, device="cuda") for _ in range(G)]
+        my_frames, sets = shard.a2a_match_sets(rank, N, NCAMS, total_frames)   # set index of (f, c) inside the received block
         assert len(my_frames) == F
         torch.cuda.synchronize()   # the zero fills above ran on torch's stream; the engine writes these tensors from its own
+        tstream = torch.cuda.current_stream().cuda_stream          # raw HIP stream the collectives are ordered on
+        exchange_bytes = nsets * (kcap * 32 + 4)
 
     def extract_submit(g):
         for i in range(SG):
             rig.extract_submit(per_slot, slot=g * SG + i)
 
     def exchange_and_match(g):
-        """Waits for group g's extraction, exchanges the descriptors and queues the matching; match_finish(g) collects it."""
-        cnt_host = np.zeros(F * NCAMS, np.int32)
-        for i in range(SG):
-            s = g * SG + i
-            rig.extract_wait(slot=s)
-            cnt_host[i * per_slot:(i + 1) * per_slot] = rig.export_descriptors(local_desc[g][i * per_slot].data_ptr(),
-                                                                               per_slot, slot=s)
-        local_cnt[g].copy_(torch.from_numpy(cnt_host))
-        if gloo:                                                # rehearsal path only
-            hd, hc = torch.zeros(all_desc[g].shape, dtype=torch.uint8), torch.zeros(all_cnt[g].shape, dtype=torch.int32)
-            dist.all_gather_into_tensor(hd, local_desc[g].cpu())
-            dist.all_gather_into_tensor(hc, local_cnt[g].cpu())
-            all_desc[g].copy_(hd)
-            all_cnt[g].copy_(hc)
+        """Waits for group g's extraction, exchanges the descriptors and queues the matching; match_finish(g) collects it.
+        Everything between the extraction's completion and the match job is stream-ordered (no host synchronisation):
+        slot streams -> torch's stream (export) -> collective -> slot streams (match)."""
+        if gloo:                                                # rehearsal path only: host tensors
+            for i in range(SG):
+                s = g * SG + i
+                rig.extract_wait(slot=s)
+                rig.export_descriptors_dev(local_desc[g][i * per_slot].data_ptr(), local_cnt[g][i * per_slot:].data_ptr(), per_slot, slot=s)
+            hd, hc = torch.zeros(recv_desc[g].shape, dtype=torch.uint8), torch.zeros(recv_cnt[g].shape, dtype=torch.int32)
+            dist.all_to_all_single(hd, local_desc[g].cpu(), recv_splits, send_splits)
+            dist.all_to_all_single(hc, local_cnt[g].cpu(), recv_splits, send_splits)
+            recv_desc[g].copy_(hd)
+            recv_cnt[g].copy_(hc)
+            torch.cuda.synchronize()
         else:
-            dist.all_gather_into_tensor(all_desc[g], local_desc[g])   # the exchange step (RCCL over xGMI)
-            dist.all_gather_into_tensor(all_cnt[g], local_cnt[g])
-        counts = all_cnt[g].cpu().numpy()                       # syncs the collective
+            for i in range(SG):
+                s = g * SG + i
+                rig.extract_wait(slot=s)
+                rig.export_descriptors_dev(local_desc[g][i * per_slot].data_ptr(), local_cnt[g][i * per_slot:].data_ptr(), per_slot,
+                                           slot=s, then_stream=tstream)
+            dist.all_to_all_single(recv_desc[g], local_desc[g], recv_splits, send_splits)   # the exchange step (RCCL over xGMI)
+            dist.all_to_all_single(recv_cnt[g], local_cnt[g], recv_splits, send_splits)
         for i in range(SG):                                     # this rank's frames, split over the group's slots
-            rig.match_external_submit(all_desc[g].data_ptr(), counts, sets[i * fps:(i + 1) * fps], slot=g * SG + i)
+            rig.match_external_dev_submit(recv_desc[g].data_ptr(), recv_cnt[g].data_ptr(), nsets, sets[i * fps:(i + 1) * fps],
+                                          slot=g * SG + i, after_stream=None if gloo else tstream)
 
     def match_finish(g):
         for i in range(SG):
@@ -211,25 +250,19 @@ def main():
         torch.cuda.synchronize()
 
     # per-kernel durations, accumulated from the HIP events the engine records on each slot's stream
-    ksum = {"k_resize": 0.0, "k_fast_cells": 0.0, "k_blur": 0.0, "k_describe": 0.0, "k_knn2": 0.0,
-            "side:k_compact": 0.0, "select_host": 0.0}
+    ksum = {k: 0.0 for k in TIMING_FIELD}
 
     def account(s):
         t = rig.timing(slot=s)
-        ksum["k_resize"] += t["pyramid_us"]
-        ksum["k_fast_cells"] += t["fast_us"]
-        ksum["side:k_compact"] += t["compact_us"]
-        ksum["k_blur"] += t["blur_us"]
-        ksum["k_describe"] += t["describe_us"]
-        ksum["k_knn2"] += t["knn2_us"]
-        ksum["select_host"] += t["select_us"]
+        for k, f in TIMING_FIELD.items():
+            ksum[k] += t[f]
 
-    def run_steps(nsteps, timed):
+    def run_steps(nsteps, timed, stage=None):
         """nsteps steps = nsteps*F frames per rank.
         N == 1: rolling submission, S jobs always in flight (a slot is resubmitted as soon as its previous job
-        is collected), so step boundaries do not drain the pipeline.
+        is collected), so step boundaries do not drain the pipeline; stage(slot), if given, runs in front of every job.
         N > 1: G slot groups rotate; extraction of steps k+1 .. k+G-2 is in flight while step k's descriptors
-        are all-gathered and matched."""
+        are exchanged and matched."""
         if DIST:
             # step k runs on group k % G.  While step k's descriptors are exchanged, step k-1 is being matched and steps
             # k+1 .. k+G-2 are being extracted; a group is re-armed (next extraction) as soon as its matching is collected.
@@ -257,6 +290,8 @@ def main():
             return
         jobs = nsteps * S
         for s in range(min(S, jobs)):
+            if stage:
+                stage(s)
             rig.process_submit(fps, slot=s)
         for j in range(jobs):
             s = j % S
@@ -264,18 +299,29 @@ def main():
             if timed:
                 account(s)
             if j + S < jobs:
+                if stage:
+                    stage(s)
                 rig.process_submit(fps, slot=s)
 
+    def timed_region(nsteps, timed, stage=None):
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(nsteps, timed, stage)
+        barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+
     run_steps(args.warmup, False)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps, True)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else "cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dts = [timed_region(args.steps, True) for _ in range(max(1, args.repeats))]
+    dt = float(np.median(dts))
+
+    if args.dump_tracks:
+        np.savez(args.dump_tracks, frames=np.array(my_frames[:fps] if DIST else list(range(fps))),
+                 **{"t%d" % i: rig.tracks(i, slot=0)[0] for i in range(fps)})
 
     if rank != 0:
         if dist is not None:
@@ -283,77 +329,112 @@ def main():
         return
 
     value = total_frames * args.steps / dt
-    launches = args.steps * SG
+    launches = args.steps * SG * len(dts)
     # workload constants for the algorithmic-byte formulas
-    lv = level_pixels(rig)
+    lv = [rig.level_size(l) for l in range(rig.nlevels)]
     Spx = sum(w * h for w, h in lv)
     S0, s_last = lv[0][0] * lv[0][1], lv[-1][0] * lv[-1][1]
+    info = rig.info()
     nimg_launch = per_slot
+    pairs_launch = fps * NCAMS * (NCAMS - 1) // 2
     Kc = np.mean([sum(len(rig.candidates(m, l, slot=0)[0]) for l in range(rig.nlevels)) for m in range(min(4, per_slot))])
     K = np.mean([rig.features(m, slot=0)[1].shape[0] for m in range(min(4, per_slot))])
-    # Which kernel dominates is decided on ISOLATED durations (one job at a time, nothing else on the GPU): with six
+    # Which kernel dominates is decided on ISOLATED durations (one job at a time, nothing else on the GPU): with several
     # jobs in flight every kernel's wall duration is stretched by whatever shares the GPU with it, and the ranking of
     # two close kernels flips from run to run.  The roofline figures themselves use the timed region, as specified.
     iso = None
     if not DIST:
-        iso = {k: 0.0 for k in ksum}
-        ISO_JOBS = 8
-        for _ in range(ISO_JOBS):
+        acc = {k: [] for k in TIMING_FIELD}
+        for _ in range(args.iso_jobs):
             rig.process_submit(fps, slot=0)
             rig.process_wait(slot=0)
             t = rig.timing(slot=0)
-            for k, f in (("k_resize", "pyramid_us"), ("k_fast_cells", "fast_us"), ("side:k_compact", "compact_us"), ("k_blur", "blur_us"),
-                         ("k_describe", "describe_us"), ("k_knn2", "knn2_us"), ("select_host", "select_us")):
-                iso[k] += t[f] / ISO_JOBS
-    gpu_kernels = {k: v for k, v in ksum.items() if k.startswith("k_")}
-    rank = {k: v for k, v in iso.items() if k.startswith("k_")} if iso else gpu_kernels
-    dominant = max(rank, key=rank.get)
-    avg_us = gpu_kernels[dominant] / launches
-    if dominant == "k_knn2":
-        unit_bytes, units = algorithmic_bytes(dominant, Spx, S0, s_last, K, Kc), 6 * fps
-    else:
-        unit_bytes, units = algorithmic_bytes(dominant, Spx, S0, s_last, K, Kc), nimg_launch
+            for k, f in TIMING_FIELD.items():
+                acc[k].append(t[f])
+        iso = {k: float(np.median(v)) for k, v in acc.items()}
+    rank_by = {k: (iso or ksum)[k] for k in GPU_KERNELS}
+    dominant = max(rank_by, key=rank_by.get)
+    avg_us = ksum[dominant] / launches
+    units = pairs_launch if dominant == "k_knn2" else nimg_launch
+    unit_bytes = algorithmic_bytes(dominant, Spx, S0, s_last, K, Kc, info["bucket_total"])
     achieved = unit_bytes * units / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")   # PMC-derived HBM bytes per launch, if measured
+    # PMC-derived HBM bytes per launch: only if profiles/traffic.json was measured on exactly these kernels
+    traffic, traffic_note = None, "profiles/traffic.json absent"
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = int(json.load(open(tpath)).get(dominant, {}).get("bytes_per_image") * nimg_launch)
-        except Exception:
-            traffic = None
+            tj = json.load(open(tpath))
+            if tj.get("kernels_sha256_16") != kernels_sha():
+                traffic_note = "profiles/traffic.json was measured on other kernel sources (sha %s, now %s): not reported" % (
+                    tj.get("kernels_sha256_16"), kernels_sha())
+            elif tj.get("config") != args.config:
+                traffic_note = "profiles/traffic.json is for config %s" % tj.get("config")
+            else:
+                traffic = int(tj[dominant]["bytes_per_image"] * nimg_launch)
+                traffic_note = tj.get("_correction", "")
+        except Exception as e:      # noqa: BLE001
+            traffic_note = "profiles/traffic.json unreadable: %s" % e
     out = {
-        "metric": "multi-cam frames/sec (4-cam 1280x720 @2000 kpts/cam, extract + intra-rig match)",
+        "metric": "multi-cam frames/sec (%d-cam %dx%d @%d kpts/cam, extract + intra-rig match)" % (NCAMS, W, H, NFEAT),
         "value": round(value, 2), "unit": "frames/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_frame": round(dt / args.steps / total_frames * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": "4-cam rig 1280x720, 2000 kpts/cam, extract + all-pairs intra-rig match (configs[1])",
+        "repeats": len(dts), "value_min": round(total_frames * args.steps / max(dts), 2),
+        "value_max": round(total_frames * args.steps / min(dts), 2),
+        "config": {"workload": cfg["label"], "name": args.config,
                    "frames_per_rank_per_step": F, "slots": S, "frames_per_launch": fps, "cameras": NCAMS, "nfeatures": NFEAT,
-                   "sharding": "single GPU" if not DIST else "camera (c+f) mod N for extraction, RCCL all-gather of descriptors, frame f mod N for matching"},
+                   "sharding": "single GPU" if not DIST else
+                   "camera (c+f) mod N for extraction, one RCCL all-to-all of descriptor sets per step (each set goes to rank f mod N only), frame f mod N for matching"},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
                      "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(unit_bytes * units),
                      "images_per_launch": nimg_launch, "fast_candidates_per_image": int(Kc),
-                     "note": "avg_launch_us is the HIP-event average over the timed region, where %d jobs share the GPU; "
-                             "isolated_* is the same kernel with one job in flight" % S},
-        "kernel_us_per_step": {k: round(v / args.steps, 2) for k, v in ksum.items()},
+                     "note": "avg_launch_us is the HIP-event average over the timed regions, where %d jobs share the GPU; "
+                             "isolated_* is the same kernel with one job in flight (median of %d)" % (S, args.iso_jobs)},
+        "kernel_us_per_step": {k: round(v / args.steps / len(dts), 2) for k, v in ksum.items()},
     }
+    if DIST:
+        out["exchange"] = {"collective": "all_to_all_single (uneven splits)", "bytes_sent_per_rank_per_step": int(exchange_bytes),
+                           "send_splits_rank0": send_splits}
     if iso:
         ia = unit_bytes * units / (iso[dominant] * 1e-6) / 1e9
         out["roofline"].update({"isolated_launch_us": round(iso[dominant], 2), "isolated_achieved": round(ia, 2),
                                 "isolated_frac": round(ia / HBM_PEAK_GBS, 5)})
         out["kernel_us_per_launch_isolated"] = {k: round(v, 2) for k, v in iso.items()}
+        # every kernel against its own algorithmic bytes (isolated): where the path stands as a whole
+        out["roofline_all_kernels_isolated"] = {
+            k: {"us": round(iso[k], 1),
+                "GBps": round(algorithmic_bytes(k, Spx, S0, s_last, K, Kc, info["bucket_total"]) *
+                              (pairs_launch if k == "k_knn2" else nimg_launch) / (iso[k] * 1e-6) / 1e9, 1)}
+            for k in GPU_KERNELS if iso[k] > 0}
+
+    if N == 1 and not DIST and not args.no_staging:
+        # the same steps with the frame hand-off in front of every batch: the reader's side of the boundary
+        plane = W * H
+        dt_st = timed_region(args.steps, False, stage=lambda s: rig.upload_staged(per_slot, slot=s))
+        dt_u8 = timed_region(args.steps, False, stage=lambda s: rig.upload(slot_imgs[s], slot=s))
+        out["value_with_staging"] = round(total_frames * args.steps / dt_st, 2)
+        out["value_with_upload_u8"] = round(total_frames * args.steps / dt_u8, 2)
+        out["pcie_gbs"] = round(total_frames * args.steps * NCAMS * plane / dt_st / 1e9, 2)
+        out["staging_note"] = ("value_with_staging: DMA out of the pinned staging planes (mcorb_rig_upload_staged) before every batch; "
+                               "value_with_upload_u8: mcorb_rig_upload_u8 from pageable memory (host copy + DMA); pcie_gbs: host->device "
+                               "bytes/s in the staged region.  `value` itself keeps its inputs resident in HBM; fed from a host it is "
+                               "bounded by these.")
 
     if N == 1 and not DIST and not args.no_cpu:
         ncpu = os.cpu_count()
-        times, t_ext, results = cpu_baseline(list(range(2 + args.cpu_frames)), NCAMS)
-        times, t_ext = np.array(times[2:]), np.array(t_ext[2:])
+        times, t_ext, results = cpu_baseline(cfg, list(range(4 + args.cpu_frames)), NCAMS)
+        times, t_ext = times[4:], t_ext[4:]
+        t1, _, _ = cpu_baseline(cfg, list(range(1 + max(4, args.cpu_frames // 8))), 1)
+        t1 = t1[1:]
         out["cpu_baseline"] = {"value": round(1.0 / float(np.median(times)), 3), "unit": "frames/s", "cores": NCAMS,
-                               "kind": "port",
-                               "sample": "%d rig frames (4-cam 1280x720 @2000) after 2 warm-ups, CPU oracle, one thread per "
-                                         "camera for extraction + matching on the caller thread; median %.1f ms (extract %.1f "
-                                         "+ match %.1f), p95 %.1f ms; host has %d logical cores"
-                                         % (len(times), np.median(times) * 1e3, np.median(t_ext) * 1e3,
-                                            np.median(times - t_ext) * 1e3, np.percentile(times, 95) * 1e3, ncpu)}
+                               "kind": "port", "value_1thread": round(1.0 / float(np.median(t1)), 3),
+                               "sample": "%d rig frames (%s) after 4 warm-ups, CPU oracle, one thread per camera for extraction + "
+                                         "matching on the caller thread; median %.1f ms (extract %.1f + match %.1f), p95 %.1f ms; "
+                                         "single thread: %d frames, median %.1f ms; host has %d logical cores"
+                                         % (len(times), cfg["label"], np.median(times) * 1e3, np.median(t_ext) * 1e3,
+                                            np.median(times - t_ext) * 1e3, np.percentile(times, 95) * 1e3, len(t1),
+                                            np.median(t1) * 1e3, ncpu)}
         # bit-exact check of every CPU-timed frame against what the GPU slots hold (slot s holds rig frames s*fps .. (s+1)*fps-1)
         ok, checked = True, 0
         for f, (res, tracks) in enumerate(results):

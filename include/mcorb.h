@@ -170,6 +170,10 @@ int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[10]);
  * caller's, e.g. an RCCL all-gather over torch.distributed).
  * Descriptor block layout on the device: [sets][kcap][32] bytes. */
 int mcorb_rig_kcap(mcorb_rig *r);
+/* sizes of one image's device structures (what the byte counts of the measurements are made of):
+ * out = {kcap, FAST cells, blur tiles, candidate slots per cell, candidate list capacity, quad-tree bucket entries,
+ *        bytes of one pyramid block, levels} */
+int mcorb_rig_info(mcorb_rig *r, int32_t out[8]);
 void *mcorb_rig_desc_device_ptr(mcorb_rig *r, int slot);
 void *mcorb_rig_stream(mcorb_rig *r, int slot);
 /* copy the first nimg descriptor sets of a slot into caller device memory
@@ -184,6 +188,17 @@ int mcorb_rig_match_external(mcorb_rig *r, int slot, const void *desc_dev, const
 /* asynchronous form: counts/sets must stay valid until mcorb_rig_match_wait(r, slot) returns */
 int mcorb_rig_match_external_submit(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts, int ntotal,
                                     const int32_t *sets, int nframes, float dist_thresh, float ratio);
+
+/* Stream-ordered forms of the two calls above, for a pipelined exchange without host synchronisation:
+ * _export_descriptors_dev enqueues the copies (descriptor sets + their int32 counts, both into caller DEVICE memory)
+ * on the slot's stream and makes `then_stream` (a HIP stream of this process, e.g. the stream the collective is issued
+ * on; NULL = block until the copies are done) wait for them;
+ * _match_external_dev_submit takes the counts from device memory and lets the slot's stream wait for everything
+ * enqueued so far on `after_stream` (the collective; NULL = the caller has synchronised already).
+ * An external block holds at most max(4096, 64 x images per slot) sets (MCORB_E_ARG beyond). */
+int mcorb_rig_export_descriptors_dev(mcorb_rig *r, int slot, void *dst_dev, int32_t *counts_dev, int nimg, void *then_stream);
+int mcorb_rig_match_external_dev_submit(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts_dev, int ntotal,
+                                        const int32_t *sets, int nframes, float dist_thresh, float ratio, void *after_stream);
 
 /* ------------------------------------------------------------------------- */
 /* Single-camera extractor: ORBextractor (ORBextractor.h:43-116)              */

@@ -203,6 +203,11 @@ class Rig:
         p = buf[:n.value]
         return ((p >> 8) & 0xfff).astype(np.int32), (p >> 20).astype(np.int32), (p & 0xff).astype(np.int32)
 
+    def info(self):
+        o = np.zeros(8, np.int32)
+        _lib.check(self.L.mcorb_rig_info(self.h_rig, o.ctypes.data))
+        return dict(zip(("kcap", "cells", "tiles", "cell_cap", "cand_cap", "bucket_total", "img_bytes", "nlevels"), (int(v) for v in o)))
+
     def timing(self, slot=0):
         t = (C.c_float * 10)()
         _lib.check(self.L.mcorb_rig_last_timing(self.h_rig, slot, t))
@@ -226,6 +231,20 @@ class Rig:
         self._keep[slot] = (counts, sets)          # must outlive the asynchronous job
         _lib.check(self.L.mcorb_rig_match_external_submit(self.h_rig, slot, desc_dev_ptr, counts.ctypes.data, len(counts),
                                                           sets.ctypes.data, len(sets), dist_thresh, ratio))
+
+    def export_descriptors_dev(self, dst_dev_ptr, counts_dev_ptr, nimg, slot=0, then_stream=None):
+        """Stream-ordered export: sets + int32 counts into caller device memory; `then_stream` (raw HIP stream handle)
+        waits for the copies."""
+        _lib.check(self.L.mcorb_rig_export_descriptors_dev(self.h_rig, slot, dst_dev_ptr, counts_dev_ptr, nimg, then_stream))
+
+    def match_external_dev_submit(self, desc_dev_ptr, counts_dev_ptr, ntotal, sets, slot=0, dist_thresh=75.0, ratio=0.85,
+                                  after_stream=None):
+        """External match with device-resident counts; the slot's stream waits for `after_stream` (the collective)."""
+        sets = np.ascontiguousarray(sets, np.int32).reshape(-1, self.ncams)
+        self._keep = getattr(self, "_keep", {})
+        self._keep[slot] = (sets,)                 # must outlive the asynchronous job
+        _lib.check(self.L.mcorb_rig_match_external_dev_submit(self.h_rig, slot, desc_dev_ptr, counts_dev_ptr, int(ntotal),
+                                                              sets.ctypes.data, len(sets), dist_thresh, ratio, after_stream))
 
     def match_wait(self, slot=0):
         _lib.check(self.L.mcorb_rig_match_wait(self.h_rig, slot))

@@ -68,11 +68,14 @@ SIGNATURES = {
     "mcorb_rig_get_candidates": (_i, [_vp, _i, _i, _i, _vp, _i, _ip]),
     "mcorb_rig_last_timing": (_i, [_vp, _i, C.POINTER(_f)]),
     "mcorb_rig_kcap": (_i, [_vp]),
+    "mcorb_rig_info": (_i, [_vp, _vp]),
     "mcorb_rig_desc_device_ptr": (_vp, [_vp, _i]),
     "mcorb_rig_stream": (_vp, [_vp, _i]),
     "mcorb_rig_export_descriptors": (_i, [_vp, _i, _vp, _vp, _i]),
     "mcorb_rig_match_external": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _f, _f]),
     "mcorb_rig_match_external_submit": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _f, _f]),
+    "mcorb_rig_export_descriptors_dev": (_i, [_vp, _i, _vp, _vp, _i, _vp]),
+    "mcorb_rig_match_external_dev_submit": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _f, _f, _vp]),
     "mcorb_create": (_i, [C.POINTER(Params), _i, _i, C.POINTER(_vp)]),
     "mcorb_destroy": (None, [_vp]),
     "mcorb_extract": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _ip, _ip]),

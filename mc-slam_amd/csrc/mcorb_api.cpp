@@ -359,6 +359,14 @@ int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[10])
 }
 
 int mcorb_rig_kcap(mcorb_rig *r) { return r ? r->rig.geom.kcap : MCORB_E_ARG; }
+int mcorb_rig_info(mcorb_rig *r, int32_t out[8])
+{
+    if (!r || !out) return MCORB_E_ARG;
+    const Geom &g = r->rig.geom;
+    out[0] = g.kcap; out[1] = g.cells; out[2] = g.tiles; out[3] = g.cellCap; out[4] = g.candCap; out[5] = g.bucketTotal;
+    out[6] = (int32_t)g.imgBytes; out[7] = g.nlevels;
+    return MCORB_OK;
+}
 void *mcorb_rig_desc_device_ptr(mcorb_rig *r, int slot)
 {
     if (!r || slot < 0 || slot >= (int)r->rig.slots.size()) return nullptr;
@@ -385,6 +393,34 @@ int mcorb_rig_match_external(mcorb_rig *r, int slot, const void *desc_dev, const
 {
     const int st = mcorb_rig_match_external_submit(r, slot, desc_dev, counts, ntotal, sets, nframes, dist_thresh, ratio);
     return st != MCORB_OK ? st : r->rig.wait(slot);
+}
+
+int mcorb_rig_match_external_dev_submit(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts_dev, int ntotal,
+                                        const int32_t *sets, int nframes, float dist_thresh, float ratio, void *after_stream)
+{
+    if (!r || !desc_dev || !counts_dev || !sets) { set_error("null argument"); return MCORB_E_ARG; }
+    Job j;
+    j.kind = Job::MATCH; j.nframes = nframes; j.dist_thresh = dist_thresh; j.ratio = ratio;
+    j.ext_desc = desc_dev; j.ext_counts_dev = counts_dev; j.ext_total = ntotal; j.ext_sets = sets;
+    j.after_stream = (hipStream_t)after_stream;
+    return r->rig.submit(slot, j);
+}
+
+int mcorb_rig_export_descriptors_dev(mcorb_rig *r, int slot, void *dst_dev, int32_t *counts_dev, int nimg, void *then_stream)
+{
+    Slot *s = get_slot(r, slot);
+    if (!s) return MCORB_E_STATE;
+    if (!dst_dev || !counts_dev || nimg < 1 || nimg > s->nimg_done) { set_error("export: bad argument"); return MCORB_E_ARG; }
+    HIPCHK(hipSetDevice(r->rig.device));
+    HIPCHK(hipMemcpyAsync(dst_dev, s->d_desc, (size_t)nimg * r->rig.geom.kcap * 32, hipMemcpyDeviceToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(counts_dev, s->d_nsel, (size_t)nimg * sizeof(int), hipMemcpyDeviceToDevice, s->st));
+    if (then_stream) {   // whatever the caller enqueues on then_stream next (the collective) runs after the two copies
+        HIPCHK(hipEventRecord(s->ev_x, s->st));
+        HIPCHK(hipStreamWaitEvent((hipStream_t)then_stream, s->ev_x, 0));
+    } else {
+        HIPCHK(hipStreamSynchronize(s->st));
+    }
+    return MCORB_OK;
 }
 
 int mcorb_rig_export_descriptors(mcorb_rig *r, int slot, void *dst_dev, int32_t *counts_host, int nimg)

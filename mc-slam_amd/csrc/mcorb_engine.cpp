@@ -393,6 +393,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
 
     const int npairs_max = std::max(1, npp * max_frames);
     const int nchunks = (geom.kcap + kKnnChunk - 1) / kKnnChunk;
+    // an external block usually holds the sets of all slots of a rank (all-to-all) or of all ranks (all-gather)
+    ext_cap = (int)align_up(std::max((size_t)4096, (size_t)64 * max_images), 64);
     for (int si = 0; si < nslots; si++) {
         Slot *s = new Slot;
         slots.push_back(s);
@@ -407,6 +409,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         // the cores the selection workers need, so those rigs sleep instead.  MCORB_SYNC=block|spin overrides.
         const char *sync_env = getenv("MCORB_SYNC");
         const bool blocking = sync_env ? !strcmp(sync_env, "block") : nslots > 8;
+        HIPCHK(hipEventCreateWithFlags(&s->ev_x, hipEventDisableTiming));
         for (int e = 0; e < 12; e++) {
             const bool waited = e == 3 || e == 10 || e == 11;
             HIPCHK(hipEventCreateWithFlags(&s->ev[e], waited && blocking ? hipEventBlockingSync : hipEventDefault));
@@ -433,7 +436,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         TRY(host_alloc(&s->h_mlist, (size_t)npairs_max * geom.kcap));
         TRY(host_alloc(&s->h_mcount, (size_t)npairs_max));
         {
-            const size_t o_nsel = 4096 * sizeof(int);
+            const size_t o_nsel = (size_t)ext_cap * sizeof(int);
             const size_t o_pairs = align_up(o_nsel + M * sizeof(int), 64);
             const size_t o_sel = align_up(o_pairs + (size_t)npairs_max * sizeof(int2), 64);
             s->ctrl_pairs_end = o_sel;
@@ -489,6 +492,7 @@ Rig::~Rig()
         (void)hipHostFree(s->h_stage);
         (void)hipHostFree(s->h_desc); (void)hipHostFree(s->h_angles);
         for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
+        if (s->ev_x) (void)hipEventDestroy(s->ev_x);
         if (s->st && !s->shared_st) (void)hipStreamDestroy(s->st);
         if (s->st_copy) (void)hipStreamDestroy(s->st_copy);
         if (s->st_dma) (void)hipStreamDestroy(s->st_dma);
@@ -500,6 +504,15 @@ Rig::~Rig()
     if (d_taps) (void)hipFree(d_taps);
 }
 
+// An upload into a slot whose job is still running would overwrite the staging buffer and level 0 between the job's
+// GPU phases (the slot's stream is idle while the host selects): refuse it like every other call on a busy slot.
+static bool slot_busy(Slot &s)
+{
+    std::lock_guard<std::mutex> lk(s.m);
+    if (s.busy) set_error("slot busy: wait for the submitted job before uploading into its slot");
+    return s.busy;
+}
+
 // Frame staging: caller memory -> pinned buffer -> hipMemcpy2DAsync into the
 // level-0 planes (replaces the clone/convert chain of MultiCameraFrame::setData).
 int Rig::upload_u8(int slot, const uint8_t *const *images, int nimg, int stride)
@@ -509,6 +522,7 @@ int Rig::upload_u8(int slot, const uint8_t *const *images, int nimg, int stride)
         return MCORB_E_ARG;
     }
     Slot &s = *slots[slot];
+    if (slot_busy(s)) return MCORB_E_STATE;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamSynchronize(s.st));   // staging buffer free again
     for (int m = 0; m < nimg; m++)
@@ -529,6 +543,7 @@ int Rig::upload_staged(int slot, int nimg)
 {
     if (slot < 0 || slot >= (int)slots.size() || nimg < 1 || nimg > max_images) { set_error("upload_staged: bad argument"); return MCORB_E_ARG; }
     Slot &s = *slots[slot];
+    if (slot_busy(s)) return MCORB_E_STATE;
     HIPCHK(hipSetDevice(device));
     const size_t plane = (size_t)W * H;
     if (geom.lv[0].pitch == W) {
@@ -550,6 +565,7 @@ int Rig::upload_f32(int slot, const float *const *images, int nimg, int stride_b
         return MCORB_E_ARG;
     }
     Slot &s = *slots[slot];
+    if (slot_busy(s)) return MCORB_E_STATE;
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipStreamSynchronize(s.st));
     const size_t row_f = (size_t)W * channels, img_f = row_f * H;
@@ -846,13 +862,17 @@ int Rig::prepare_match(Slot &s, const Job &j)
     s.match_sets.resize((size_t)j.nframes * C);
     s.match_counts.resize((size_t)j.nframes * C);
     if (ext) {
-        if (j.ext_total < 1 || j.ext_total > 4096 || !j.ext_counts || !j.ext_sets) { set_error("match: bad external block"); return MCORB_E_ARG; }
-        for (int i = 0; i < j.ext_total; i++) s.h_extcounts[i] = std::min(std::max(j.ext_counts[i], 0), geom.kcap);
+        if (j.ext_total < 1 || j.ext_total > ext_cap || (!j.ext_counts && !j.ext_counts_dev) || !j.ext_sets) {
+            set_error("match: bad external block (at most " + std::to_string(ext_cap) + " sets = max(4096, 64 x images per slot))");
+            return MCORB_E_ARG;
+        }
+        if (j.ext_counts)
+            for (int i = 0; i < j.ext_total; i++) s.h_extcounts[i] = std::min(std::max(j.ext_counts[i], 0), geom.kcap);
         for (int i = 0; i < j.nframes * C; i++) {
             const int set = j.ext_sets[i];
             if (set < 0 || set >= j.ext_total) { set_error("match: set index out of range"); return MCORB_E_ARG; }
             s.match_sets[i] = set;
-            s.match_counts[i] = s.h_extcounts[set];
+            s.match_counts[i] = j.ext_counts ? s.h_extcounts[set] : 0;   // device-resident counts arrive with the job (finish_match)
         }
     } else {
         for (int i = 0; i < j.nframes * C; i++) { s.match_sets[i] = i; s.match_counts[i] = s.h_nsel[i]; }
@@ -871,6 +891,14 @@ int Rig::enqueue_match(Slot &s, const Job &j, bool ctrl_on_device)
     if (!ctrl_on_device) {
         TRY(prepare_match(s, j));
         HIPCHK(hipMemcpyAsync(s.d_ctrl, s.h_ctrl, s.ctrl_pairs_end, hipMemcpyHostToDevice, s.st));
+    }
+    if (j.after_stream) {   // the block is being produced on another stream (a collective): order this stream behind it
+        HIPCHK(hipEventRecord(s.ev_x, j.after_stream));
+        HIPCHK(hipStreamWaitEvent(s.st, s.ev_x, 0));
+    }
+    if (j.ext_counts_dev) {
+        HIPCHK(hipMemcpyAsync(s.d_extcounts, j.ext_counts_dev, (size_t)j.ext_total * sizeof(int), hipMemcpyDeviceToDevice, s.st));
+        HIPCHK(hipMemcpyAsync(s.h_extcounts, j.ext_counts_dev, (size_t)j.ext_total * sizeof(int), hipMemcpyDeviceToHost, s.st));
     }
     if (s.npairs_done == 0) return MCORB_OK;
     const bool ext = j.ext_desc != nullptr;
@@ -950,8 +978,10 @@ void Rig::merge_tracks(Slot &s, int f, const EpipolarGate *gate, std::vector<int
 // after the k-NN tables landed.
 int Rig::finish_match(Slot &s, const Job &j)
 {
-    (void)j;
     HostProf::Scope prof(2);
+    if (j.ext_counts_dev)   // the counts came over with the job's own stream; the k-NN kernels clamped them the same way
+        for (size_t i = 0; i < s.match_sets.size(); i++)
+            s.match_counts[i] = std::min(std::max(s.h_extcounts[s.match_sets[i]], 0), geom.kcap);
     (void)ncams;
     auto filter_pair = [&](int pi, int) {   // BruteForceMatch's accept loop for one camera pair (pair index within the job)
         // k_knn2_finalize already compacted the accepted pairs in query order: unpack query << 16 | train

@@ -76,6 +76,10 @@ struct Job {
     const int32_t *ext_counts = nullptr;
     int ext_total = 0;
     const int32_t *ext_sets = nullptr;
+    // device-resident form (no host synchronisation between the collective and the match): the counts live in device
+    // memory, and the slot's stream first waits for everything enqueued so far on `after_stream` (the collective)
+    const int32_t *ext_counts_dev = nullptr;
+    hipStream_t after_stream = nullptr;
 };
 
 class Rig;
@@ -85,6 +89,7 @@ struct Slot {
     int index = 0;
     bool shared_st = false;
     hipStream_t st = nullptr, st_copy = nullptr, st_dma = nullptr;   // compute; PCIe-bound compaction kernel; D2H copies only
+    hipEvent_t ev_x = nullptr;   // cross-stream hand-offs with the caller's streams (export / external match)
     hipEvent_t ev[12] = {};  // 0 start, 1 pyramid done, 2 FAST done, 3 compact done, 4 blur done, 5/6 describe(+D2H), 7 knn2 start, 8 knn2 done, 9 finalize done
     // device
     uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_desc = nullptr;
@@ -103,7 +108,7 @@ struct Slot {
     uint32_t *h_mlist = nullptr;     // per pair: accepted (query << 16 | train), query order (k_knn2_finalize)
     int *h_mcount = nullptr;
     // control block: one pinned host buffer + one device mirror, copied with a single
-    // hipMemcpyAsync: [extcounts 4096 ints][nsel][pairs][sel]
+    // hipMemcpyAsync: [extcounts ext_cap ints][nsel][pairs][sel]
     uint8_t *h_ctrl = nullptr, *d_ctrl = nullptr;
     size_t ctrl_pairs_end = 0, ctrl_bytes = 0;
     int *h_extcounts = nullptr, *h_nsel = nullptr;
@@ -162,6 +167,7 @@ public:
     Tables tab;
     Geom geom;
     int ncams = 0, W = 0, H = 0, max_frames = 0, max_images = 0, npp = 0 /* pairs per frame */;
+    int ext_cap = 0;   // descriptor sets an external block may hold (mcorb_rig_match_external*)
     int device = 0;
     ResizeTap *d_taps = nullptr;
     SelectParams selp[kMaxLevels];         // per-level DistributeOctTree constants + bucketing depth

@@ -986,7 +986,7 @@ __global__ __launch_bounds__(kKnnWG) void k_knn2(const uint8_t *__restrict__ des
     const int lane = threadIdx.x;   // kKnnWG / 64 waves share one staged train chunk
     const int pair = blockIdx.z, chunk = blockIdx.y;
     const int2 qt = pairs[pair];
-    const int nq = counts[qt.x], nt = counts[qt.y];
+    const int nq = min(max(counts[qt.x], 0), kcap), nt = min(max(counts[qt.y], 0), kcap);   // (external counts: never trust a length)
     const int q0 = blockIdx.x * (kKnnWG * kKnnQpl) + lane;
     const int t0 = chunk * kKnnChunk;
     if (blockIdx.x * (kKnnWG * kKnnQpl) >= nq) return;
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(1024) void k_knn2_finalize(const uint2 *__restrict_
     __shared__ int s_run;
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int2 qt = pairs[pair];
-    const int nq = counts[qt.x], nt = counts[qt.y];
+    const int nq = min(max(counts[qt.x], 0), kcap), nt = min(max(counts[qt.y], 0), kcap);
     const int used = (nt + kKnnChunk - 1) / kKnnChunk;
     if (tid == 0) s_run = 0;
     __syncthreads();

@@ -6,6 +6,11 @@ One process per GPU.  A step handles `frames_per_rank * world` rig frames:
   * each rank exports its descriptor sets in (frame, camera) order; ONE all-gather makes
     every rank hold all sets: set index = owner * sets_per_rank + local position,
   * frame f is matched (all camera pairs + track merge) on rank f mod world.
+
+The all-gather lands every rank's sets on every rank although a rank only matches 1/world of the frames.  The
+`a2a_*` functions describe the exchange that moves exactly what the matching needs (an all-to-all with uneven
+splits): a rank orders its images by (destination rank, frame, camera), so its export buffer is already grouped
+by destination, and receives, from every source rank in turn, the sets of the frames it matches.
 """
 import numpy as np
 
@@ -43,5 +48,42 @@ def frames_of_rank(rank, world, total_frames):
 def match_sets(rank, world, ncams, total_frames):
     """(frames matched on this rank, int32 array [nframes][ncams] of gathered set indices)."""
     idx = gathered_set_index(world, ncams, total_frames)
+    fr = frames_of_rank(rank, world, total_frames)
+    return fr, np.array([[idx[(f, c)] for c in range(ncams)] for f in fr], np.int32).reshape(len(fr), ncams)
+
+
+# ---- all-to-all: every set travels only to the rank that matches its frame ----
+def dest(f, world):
+    return f % world
+
+
+def a2a_images_of_rank(rank, world, ncams, total_frames):
+    """(frame, camera) pairs rank `rank` extracts, ordered by (destination rank, frame, camera): the local image order,
+    which makes the exported descriptor block a ready-made all-to-all send buffer."""
+    return sorted(images_of_rank(rank, world, ncams, total_frames), key=lambda fc: (dest(fc[0], world), fc[0], fc[1]))
+
+
+def a2a_send_splits(rank, world, ncams, total_frames):
+    """number of sets rank `rank` sends to each destination rank"""
+    n = [0] * world
+    for f, _ in images_of_rank(rank, world, ncams, total_frames):
+        n[dest(f, world)] += 1
+    return n
+
+
+def a2a_recv_splits(rank, world, ncams, total_frames):
+    """number of sets rank `rank` receives from each source rank"""
+    return [a2a_send_splits(src, world, ncams, total_frames)[rank] for src in range(world)]
+
+
+def a2a_match_sets(rank, world, ncams, total_frames):
+    """(frames matched on this rank, int32 [nframes][ncams] of set indices inside the RECEIVED block): the block is the
+    concatenation over source ranks of what each sends here, every part in the sender's (frame, camera) order."""
+    idx, base = {}, 0
+    for src in range(world):
+        part = [fc for fc in a2a_images_of_rank(src, world, ncams, total_frames) if dest(fc[0], world) == rank]
+        for i, fc in enumerate(part):
+            idx[fc] = base + i
+        base += len(part)
     fr = frames_of_rank(rank, world, total_frames)
     return fr, np.array([[idx[(f, c)] for c in range(ncams)] for f in fr], np.int32).reshape(len(fr), ncams)

@@ -1,6 +1,6 @@
-"""world_size-2 gloo test of the multi-GPU data path (camera sharding -> all-gather of
-per-camera descriptors -> per-frame matching), with the CPU oracle standing in for the GPU
-stages.  What is under test is the placement / indexing logic bench.py uses for N > 1
+"""world_size-2 gloo test of the multi-GPU data path (camera sharding -> exchange of
+per-camera descriptors [all-gather, and the all-to-all bench.py uses] -> per-frame matching), with the CPU oracle
+standing in for the GPU stages.  What is under test is the placement / indexing logic bench.py uses for N > 1
 (mc-slam_amd/sharding.py) and that the exchange reproduces the single-process result."""
 import os
 import sys
@@ -22,6 +22,39 @@ def _extract(f, c):
     mono, k, d = O.OracleExtractor(NFEAT, 1.2, NLEV)(img)
     assert mono >= 0 and len(d) <= KCAP
     return d
+
+
+def _worker_a2a(rank, world, port, q):
+    """the exchange bench.py uses: every set goes only to the rank that matches its frame (uneven all-to-all)"""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import torch
+    import torch.distributed as dist
+    import oracle_lib as O
+    shard = import_module("mc-slam_amd.sharding")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = FRAMES_PER_RANK * world
+    mine = shard.a2a_images_of_rank(rank, world, NCAMS, total)
+    send, recv = shard.a2a_send_splits(rank, world, NCAMS, total), shard.a2a_recv_splits(rank, world, NCAMS, total)
+    local = torch.zeros((len(mine), KCAP, 32), dtype=torch.uint8)
+    cnt = torch.zeros(len(mine), dtype=torch.int32)
+    for i, (f, c) in enumerate(mine):
+        d = _extract(f, c)
+        local[i, :len(d)] = torch.from_numpy(d)
+        cnt[i] = len(d)
+    block = torch.zeros((sum(recv), KCAP, 32), dtype=torch.uint8)
+    counts = torch.zeros(sum(recv), dtype=torch.int32)
+    dist.all_to_all_single(block, local, recv, send)      # the exchange step
+    dist.all_to_all_single(counts, cnt, recv, send)
+    block, counts = block.numpy(), counts.numpy()
+    frames, sets = shard.a2a_match_sets(rank, world, NCAMS, total)
+    out = {}
+    for f, row in zip(frames, sets):
+        out[f] = O.intra_matches([block[s, :counts[s]] for s in row])
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
 
 
 def _worker(rank, world, port, q):
@@ -59,14 +92,14 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_sharded_pipeline_equals_single_process(world):
+@pytest.mark.parametrize("world,worker", [(2, "allgather"), (2, "a2a")])
+def test_sharded_pipeline_equals_single_process(world, worker):
     import torch.multiprocessing as mp
     import oracle_lib as O
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + (7 if worker == "a2a" else 0)
+    procs = [ctx.Process(target=_worker if worker == "allgather" else _worker_a2a, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}
@@ -102,3 +135,28 @@ def test_placement_is_balanced_and_consistent(world, ncams, fpr):
             if world >= ncams:                                    # one camera per GPU within a frame
                 assert len({shard.owner(c, f, world) for c in range(ncams)}) == ncams
     assert sorted(seen) == list(range(total))
+
+
+@pytest.mark.parametrize("world,ncams,fpr", [(1, 4, 8), (2, 4, 8), (4, 4, 8), (8, 4, 8), (8, 8, 4), (2, 3, 2), (3, 5, 3)])
+def test_all_to_all_placement(world, ncams, fpr):
+    """the all-to-all moves each set exactly once, to the rank that matches its frame; send / receive splits agree;
+    the received block's index map is a bijection"""
+    shard = import_module("mc-slam_amd.sharding")
+    total = fpr * world
+    sends = [shard.a2a_send_splits(r, world, ncams, total) for r in range(world)]
+    for r in range(world):
+        mine = shard.a2a_images_of_rank(r, world, ncams, total)
+        assert sorted(mine) == sorted(shard.images_of_rank(r, world, ncams, total))
+        assert [shard.dest(f, world) for f, _ in mine] == sorted(shard.dest(f, world) for f, _ in mine)   # grouped by destination
+        assert sum(sends[r]) == len(mine) == fpr * ncams
+        recv = shard.a2a_recv_splits(r, world, ncams, total)
+        assert recv == [sends[src][r] for src in range(world)] and sum(recv) == fpr * ncams    # weak scaling: fixed volume
+        frames, sets = shard.a2a_match_sets(r, world, ncams, total)
+        assert frames == shard.frames_of_rank(r, world, total) and sets.shape == (fpr, ncams)
+        assert sorted(sets.ravel().tolist()) == list(range(fpr * ncams))
+        # simulate the transport: concatenate what every source sends here, look the sets up through the index map
+        block = []
+        for src in range(world):
+            block += [fc for fc in shard.a2a_images_of_rank(src, world, ncams, total) if shard.dest(fc[0], world) == r]
+        for f, row in zip(frames, sets):
+            assert [block[i] for i in row] == [(f, c) for c in range(ncams)]

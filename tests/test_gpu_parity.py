@@ -461,3 +461,30 @@ def test_sharded_path_export_gather_match_external(mc):
     for rg in rigs + [fused]:
         rg.close()
     hip.hipFree(gathered)
+
+
+def test_bench_sharded_path_in_a_fresh_process(tmp_path):
+    """bench.py's N > 1 code path (stream-ordered export -> RCCL all-to-all -> external match with device-resident
+    counts), run in a child process (fresh HIP/RCCL state, torch initialised first) at world size 1, must produce the
+    tracks of the fused single-GPU path for the same frames."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = {}
+    for name, extra in (("dist", ["--force-dist"]), ("fused", [])):
+        dump = str(tmp_path / (name + ".npz"))
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--repeats", "1", "--frames", "8", "--slots",
+               "4" if name == "dist" else "1", "--no-cpu", "--no-latency", "--no-staging", "--iso-jobs", "1", "--dump-tracks", dump] + extra
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        outs[name] = (json.loads(line), np.load(dump))
+    jd, td = outs["dist"]
+    jf, tf = outs["fused"]
+    assert jd["n_gpus"] == 1 and "all-to-all" in jd["config"]["sharding"] and jd["value"] > 0
+    # dist: 4 slots = 4 groups x 1 slot, 8 frames per group-slot; slot 0 holds this rank's frames 0..7 in both runs
+    assert np.array_equal(td["frames"], tf["frames"])
+    for i in range(len(tf["frames"])):
+        assert np.array_equal(td["t%d" % i], tf["t%d" % i]), "tracks of frame %d differ between the sharded and the fused path" % i
