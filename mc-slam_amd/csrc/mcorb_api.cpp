@@ -326,7 +326,7 @@ int mcorb_rig_get_candidates(mcorb_rig *r, int slot, int m, int level, uint32_t 
     if (!s) return MCORB_E_STATE;
     const Geom &g = r->rig.geom;
     if (m < 0 || m >= s->nimg_done || level < 0 || level >= g.nlevels) { set_error("bad candidate request"); return MCORB_E_ARG; }
-    const int *lo = s->h_lvloff + (size_t)m * (kMaxLevels + 1);
+    const int *lo = s->tbl(m) + kTblLvlOff;
     const int n = lo[level + 1] - lo[level];
     if (n_out) *n_out = n;
     if (n > cap) { set_error("candidate buffer too small"); return MCORB_E_CAP; }

@@ -25,7 +25,14 @@ __host__ __device__ inline int cand_resp(uint32_t p) { return (int)(p & 0xffu); 
 // pos = index of that candidate in the level's bucket-sorted list.  key == 0: empty bucket.
 // val = that candidate itself (packed y | x | response), so the host can build the keypoint without the list.
 constexpr int kPickOrderMask = (1 << 23) - 1;
-struct BucketBest { uint32_t key, pos, val; };
+struct BucketBest { uint32_t key, pos, val; };   // host statement (test hook): also the winner's position
+struct BucketWin { uint32_t key, val; };         // what k_compact ships per bucket: 8 bytes
+
+// Per-image table block k_compact fills in DEVICE memory; one DMA per batch brings the blocks to the host:
+// ints [0, 17) level offsets into the image's candidate list (+ the total), [17, 33) `shipped` flag per level,
+// [kTblHead, kTblHead + bucketTotal) bucket start offsets, then bucketTotal BucketWin records.
+constexpr int kTblLvlOff = 0, kTblShipped = kMaxLevels + 1, kTblHead = 48;
+__host__ __device__ inline int tbl_ints(int bucketTotal) { return (kTblHead + 3 * bucketTotal + 15) & ~15; }
 
 // result of the vocabulary descent of one descriptor: word id and weight of the leaf it reached (word < 0 never
 // happens for a well-formed tree), and the node id `levelsup` levels above the leaves (FeatureVector key)
@@ -53,6 +60,8 @@ struct LevelGeom {
     int bucket0;         // index of this level's first bucket-start entry inside one image (nBuckets+1 entries)
     int quota;           // mnFeaturesPerLevel[level] (DistributeOctTree's N): candidates are shipped to the host only when
                          // fewer than `quota` buckets are non-empty, i.e. when the tree can go deeper than the bucketing
+    // path-code tables (u16 units inside the rig's table array): code(x, y) = lut[lutx + x] | lut[luty + y], see path_code_tables()
+    uint32_t lutx, luty;
 };
 
 struct Geom {
@@ -94,6 +103,18 @@ __host__ __device__ inline uint32_t path_code(int x, int y, int W0, int H0, int 
         code = (code << 2) | (uint32_t)(qx + 2 * qy);
     }
     return code;
+}
+
+// path_code() decides the x half (root node + one bit per split) from x alone and the y half from y alone, so
+//   path_code(x, y) == tx[x] | ty[y]   with   tx[x] = root << 2*depth | x-bits on the even positions, ty[y] = y-bits on the odd ones.
+// The tables are built on the host with path_code() itself (x in [0, W0), y in [0, H0)): k_compact reads two table entries
+// instead of a float division and `depth` split iterations per candidate.
+inline void path_code_tables(int W0, int H0, int nIni, float hX, int depth, uint16_t *tx, uint16_t *ty)
+{
+    uint32_t ymask = 0;
+    for (int d = 0; d < depth; d++) ymask |= 2u << (2 * d);
+    for (int x = 0; x < W0; x++) tx[x] = (uint16_t)(path_code(x, 0, W0, H0, nIni, hX, depth) & ~ymask);
+    for (int y = 0; y < H0; y++) ty[y] = (uint16_t)(path_code(0, y, W0, H0, nIni, hX, depth) & ymask);
 }
 
 // resize table entries (built on the host exactly as cv::resize builds xofs/ialpha, yofs/ibeta)

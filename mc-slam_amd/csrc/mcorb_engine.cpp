@@ -120,10 +120,12 @@ void build_resize_axis(int ssize, int dsize, bool is_x, std::vector<ResizeTap> &
     while ((out.size() - first) % pad_to) out.push_back(ResizeTap{0, 0, 0, 0});
 }
 
-int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g, std::vector<ResizeTap> &taps)
+int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g, std::vector<ResizeTap> &taps,
+                   std::vector<uint16_t> *lut)
 {
     memset(&g, 0, sizeof(g));
     taps.clear();
+    if (lut) lut->clear();
     g.nlevels = t.nlevels;
     size_t off = 0;
     int cells = 0, tiles = 0, cellCap = 4, buckets = 0;
@@ -157,6 +159,14 @@ int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g
         L.bucket0 = buckets;
         L.quota = t.quota[l];
         buckets += L.nBuckets + 1;
+        if (lut) {   // path-code tables of this level (k_compact): code(x, y) = lut[L.lutx + x] | lut[L.luty + y]
+            const int W0 = L.maxBorderX - kMinBorder, H0 = L.maxBorderY - kMinBorder;
+            L.lutx = (uint32_t)lut->size();
+            L.luty = L.lutx + (uint32_t)W0;
+            lut->resize(lut->size() + (size_t)W0 + H0);
+            path_code_tables(W0, H0, L.nIni, L.hX, L.depth, lut->data() + L.lutx, lut->data() + L.luty);
+            while (lut->size() & 7) lut->push_back(0);
+        }
         if (L.w > 4096 || L.h > 4096) { set_error("image larger than 4096 px"); return MCORB_E_SIZE; }
         L.pitch = (int)align_up((size_t)L.w, 64);
         L.off = (uint32_t)off;
@@ -355,7 +365,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     HIPCHK(hipSetDevice(device));
     TRY(compute_tables(p, tab));
     std::vector<ResizeTap> taps;
-    TRY(build_geometry(p, tab, W, H, geom, taps));
+    std::vector<uint16_t> lut;
+    TRY(build_geometry(p, tab, W, H, geom, taps, &lut));
     for (int l = 0; l < geom.nlevels; l++)
         selp[l] = make_select_params(kMinBorder, geom.lv[l].maxBorderX, kMinBorder, geom.lv[l].maxBorderY, tab.quota[l],
                                      geom.lv[l].wCell, geom.lv[l].hCell);
@@ -379,6 +390,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     }
     TRY(dev_alloc(&d_taps, taps.size()));
     HIPCHK(hipMemcpy(d_taps, taps.data(), taps.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
+    TRY(dev_alloc(&d_lut, lut.size() + 8));
+    HIPCHK(hipMemcpy(d_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     HIPCHK(upload_umax(tab.umax));
 
     int nthreads = p.host_threads > 0 ? p.host_threads : (int)std::thread::hardware_concurrency();
@@ -410,6 +423,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         const char *sync_env = getenv("MCORB_SYNC");
         const bool blocking = sync_env ? !strcmp(sync_env, "block") : nslots > 8;
         HIPCHK(hipEventCreateWithFlags(&s->ev_x, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_c, hipEventDefault));
         for (int e = 0; e < 12; e++) {
             const bool waited = e == 3 || e == 10 || e == 11;
             HIPCHK(hipEventCreateWithFlags(&s->ev[e], waited && blocking ? hipEventBlockingSync : hipEventDefault));
@@ -422,15 +436,14 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         TRY(dev_alloc(&s->d_cellkp, M * geom.cells * geom.cellCap));
         TRY(dev_alloc(&s->d_cellcnt, M * geom.cells));
         TRY(dev_alloc(&s->d_sorted, M * geom.candCap));
-        TRY(host_alloc(&s->h_bstart, M * geom.bucketTotal));
-        TRY(host_alloc(&s->h_bbest, M * geom.bucketTotal));
+        s->tbl_ints_per_image = tbl_ints(geom.bucketTotal);
+        TRY(dev_alloc(&s->d_tbl, M * s->tbl_ints_per_image));
+        TRY(host_alloc(&s->h_tbl, M * s->tbl_ints_per_image));
         TRY(dev_alloc(&s->d_desc, M * geom.kcap * 32));
         HIPCHK(hipMemset(s->d_desc, 0, M * geom.kcap * 32));
         TRY(dev_alloc(&s->d_angles, M * geom.kcap));
         TRY(dev_alloc(&s->d_part, (size_t)npairs_max * nchunks * geom.kcap));
         TRY(host_alloc(&s->h_cand, M * geom.hostCandCap));
-        TRY(host_alloc(&s->h_lvloff, M * (kMaxLevels + 1)));
-        TRY(host_alloc(&s->h_shipped, M * kMaxLevels));
         TRY(host_alloc(&s->h_overflow, 16));
         TRY(dev_alloc(&s->d_knn, (size_t)npairs_max * geom.kcap));
         TRY(host_alloc(&s->h_mlist, (size_t)npairs_max * geom.kcap));
@@ -486,13 +499,14 @@ Rig::~Rig()
         if (s->st_copy) (void)hipStreamSynchronize(s->st_copy);
         if (s->st_dma) (void)hipStreamSynchronize(s->st_dma);
         (void)hipFree(s->d_pyr); (void)hipFree(s->d_blur); (void)hipFree(s->d_desc); (void)hipFree(s->d_cellkp);
-        (void)hipFree(s->d_cellcnt); (void)hipFree(s->d_sorted); (void)hipHostFree(s->h_bstart); (void)hipHostFree(s->h_bbest); (void)hipFree(s->d_angles); (void)hipFree(s->d_part); (void)hipFree(s->d_f32);
-        (void)hipHostFree(s->h_cand); (void)hipHostFree(s->h_lvloff); (void)hipHostFree(s->h_shipped); (void)hipHostFree(s->h_overflow);
+        (void)hipFree(s->d_cellcnt); (void)hipFree(s->d_sorted); (void)hipFree(s->d_tbl); (void)hipHostFree(s->h_tbl); (void)hipFree(s->d_angles); (void)hipFree(s->d_part); (void)hipFree(s->d_f32);
+        (void)hipHostFree(s->h_cand); (void)hipHostFree(s->h_overflow);
         (void)hipFree(s->d_knn); (void)hipHostFree(s->h_mlist); (void)hipHostFree(s->h_mcount); (void)hipHostFree(s->h_ctrl); (void)hipFree(s->d_ctrl);
         (void)hipHostFree(s->h_stage);
         (void)hipHostFree(s->h_desc); (void)hipHostFree(s->h_angles);
         for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
         if (s->ev_x) (void)hipEventDestroy(s->ev_x);
+        if (s->ev_c) (void)hipEventDestroy(s->ev_c);
         if (s->st && !s->shared_st) (void)hipStreamDestroy(s->st);
         if (s->st_copy) (void)hipStreamDestroy(s->st_copy);
         if (s->st_dma) (void)hipStreamDestroy(s->st_dma);
@@ -502,6 +516,7 @@ Rig::~Rig()
     delete pool;
     for (auto *sc : scratch) delete sc;
     if (d_taps) (void)hipFree(d_taps);
+    if (d_lut) (void)hipFree(d_lut);
 }
 
 // An upload into a slot whose job is still running would overwrite the staging buffer and level 0 between the job's
@@ -695,11 +710,14 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
     HIPCHK(hipEventRecord(s.ev[1], s.st));
     launch_fast(s.st, s.d_pyr, geom, params.ini_th_fast, params.min_th_fast, s.d_cellkp, s.d_cellcnt, j.nimg);
     HIPCHK(hipEventRecord(s.ev[2], s.st));
-    // compaction writes the candidates over PCIe into host-mapped memory: run it on the side stream so
-    // the blur (which does not depend on it) overlaps the transfer
-    HIPCHK(hipStreamWaitEvent(s.st_copy, s.ev[2], 0));
-    launch_compact(s.st_copy, s.d_cellkp, s.d_cellcnt, geom, s.d_sorted, s.h_cand, s.h_lvloff, s.h_bstart, s.h_bbest, s.h_shipped, s.h_overflow,
-                   j.nimg);
+    // compaction fills the per-image table blocks in device memory (a short kernel: it runs on the compute stream, ahead
+    // of the blur); the DMA that takes the blocks to the host runs on the side stream while the blur computes.
+    static const bool side = getenv("MCORB_COMPACT_SIDE") != nullptr;   // round-1 placement, for comparison
+    if (side) HIPCHK(hipStreamWaitEvent(s.st_copy, s.ev[2], 0));
+    launch_compact(side ? s.st_copy : s.st, s.d_cellkp, s.d_cellcnt, geom, d_lut, s.d_sorted, s.h_cand, s.d_tbl, s.h_overflow, j.nimg);
+    HIPCHK(hipEventRecord(s.ev_c, side ? s.st_copy : s.st));
+    if (!side) HIPCHK(hipStreamWaitEvent(s.st_copy, s.ev_c, 0));
+    HIPCHK(hipMemcpyAsync(s.h_tbl, s.d_tbl, (size_t)j.nimg * s.tbl_ints_per_image * sizeof(int), hipMemcpyDeviceToHost, s.st_copy));
     HIPCHK(hipEventRecord(s.ev[3], s.st_copy));
     launch_blur(s.st, s.d_pyr, s.d_blur, geom, j.nimg);
     HIPCHK(hipEventRecord(s.ev[4], s.st));
@@ -735,23 +753,25 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     pool->parallel_for(nimg * parts, [&](int task, int w) {
         HostProf::Scope prof_task(0);
         const int m = task / parts, part = task - m * parts;
-        const int *lo = s.h_lvloff + (size_t)m * (kMaxLevels + 1);
-        const int *shp = s.h_shipped + (size_t)m * kMaxLevels;
+        const int *tb = s.tbl(m);
+        const int *lo = tb + kTblLvlOff, *shp = tb + kTblShipped;
+        const int *bst = tb + kTblHead;
+        const BucketWin *win = reinterpret_cast<const BucketWin *>(tb + kTblHead + geom.bucketTotal);
         {
-            // the GPU wrote these over PCIe, so they sit in DRAM, not in this core's caches: stream them in with one
+            // the DMA engine wrote these over PCIe, so they sit in DRAM, not in this core's caches: stream them in with one
             // demand load per cache line instead of taking the misses one by one below (software prefetches were
             // measured slower, most get dropped)
             uint32_t touch = 0;
             const uint32_t *c = s.h_cand + (size_t)m * geom.hostCandCap;
-            const uint32_t *b1 = reinterpret_cast<const uint32_t *>(s.h_bstart + (size_t)m * geom.bucketTotal);
-            const uint32_t *b2 = reinterpret_cast<const uint32_t *>(s.h_bbest + (size_t)m * geom.bucketTotal);
+            const uint32_t *b1 = reinterpret_cast<const uint32_t *>(bst);
+            const uint32_t *b2 = reinterpret_cast<const uint32_t *>(win);
             for (int l = 0; l < L; l++) {
                 if (part_of[l] != part) continue;
                 if (shp[l])
                     for (int i = lo[l], e = lo[l + 1]; i < e; i += 16) touch += c[i];
                 const int b0 = geom.lv[l].bucket0, nb = geom.lv[l].nBuckets + 1;
                 for (int i = b0; i < b0 + nb; i += 16) touch += b1[i];
-                for (int i = 3 * b0; i < 3 * (b0 + nb); i += 16) touch += b2[i];
+                for (int i = 2 * b0; i < 2 * (b0 + nb); i += 16) touch += b2[i];
             }
             s.touch_sink[task & 15] = touch;   // keeps the loads alive
         }
@@ -766,8 +786,7 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
             int r = 0;
             if (n > 0)
                 r = select_octree(shp[level] ? s.h_cand + (size_t)m * geom.hostCandCap + lo[level] : nullptr,
-                                  s.h_bstart + (size_t)m * geom.bucketTotal + geom.lv[level].bucket0,
-                                  s.h_bbest + (size_t)m * geom.bucketTotal + geom.lv[level].bucket0, n, selp[level],
+                                  bst + geom.lv[level].bucket0, win + geom.lv[level].bucket0, n, selp[level],
                                   idx.data(), out.data(), *scratch[w]);
             if (r == -3) { bad.store(3); r = 0; }
             if (r < 0) { bad.store(1); r = 0; }
@@ -837,7 +856,7 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     s.nimg_done = nimg;
     float a = 0, b = 0, c = 0, t = 0;
     (void)hipEventElapsedTime(&a, s.ev[0], s.ev[2]);
-    (void)hipEventElapsedTime(&b, s.ev[2], s.ev[4]);
+    (void)hipEventElapsedTime(&b, s.ev_c, s.ev[4]);
     (void)hipEventElapsedTime(&c, s.ev[5], s.ev[6]);
     s.timing[0] = a * 1000.f;
     s.timing[2] = (b + c) * 1000.f;
@@ -845,7 +864,7 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     s.timing[9] = c * 1000.f;   // k_describe
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[1]); s.timing[4] = t * 1000.f;   // pyramid launches
     (void)hipEventElapsedTime(&t, s.ev[1], s.ev[2]); s.timing[5] = t * 1000.f;   // k_fast_cells
-    (void)hipEventElapsedTime(&t, s.ev[2], s.ev[3]); s.timing[6] = t * 1000.f;   // k_compact
+    (void)hipEventElapsedTime(&t, s.ev[2], s.ev_c); s.timing[6] = t * 1000.f;   // k_compact (the table DMA behind it is not included)
     return MCORB_OK;
 }
 

@@ -36,7 +36,9 @@ int compute_tables(const mcorb_params &p, Tables &t);
 void build_resize_axis(int ssize, int dsize, bool is_x, std::vector<ResizeTap> &out, int pad_to);
 
 // level / cell / tile geometry for W x H; returns MCORB_OK or MCORB_E_SIZE
-int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g, std::vector<ResizeTap> &taps);
+// lut (optional): receives the path-code tables of all levels (LevelGeom::lutx / luty index into it)
+int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g, std::vector<ResizeTap> &taps,
+                   std::vector<uint16_t> *lut = nullptr);
 
 class WorkerPool {
 public:
@@ -90,6 +92,7 @@ struct Slot {
     bool shared_st = false;
     hipStream_t st = nullptr, st_copy = nullptr, st_dma = nullptr;   // compute; PCIe-bound compaction kernel; D2H copies only
     hipEvent_t ev_x = nullptr;   // cross-stream hand-offs with the caller's streams (export / external match)
+    hipEvent_t ev_c = nullptr;   // k_compact finished (the table DMA follows it on the side stream)
     hipEvent_t ev[12] = {};  // 0 start, 1 pyramid done, 2 FAST done, 3 compact done, 4 blur done, 5/6 describe(+D2H), 7 knn2 start, 8 knn2 done, 9 finalize done
     // device
     uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_desc = nullptr;
@@ -100,10 +103,13 @@ struct Slot {
     size_t f32_bytes = 0;
     // host, device-mapped (kernels write/read these directly over PCIe)
     uint32_t *h_cand = nullptr;
-    int *h_lvloff = nullptr, *h_overflow = nullptr, *h_bstart = nullptr;
-    int *h_shipped = nullptr;        // per (image, level): 1 if k_compact copied the level's candidate list to h_cand
+    int *h_overflow = nullptr;
+    // k_compact's per-image table blocks (level offsets, shipped flags, bucket starts, bucket winners; layout in
+    // mcorb_common.h): written to d_tbl by the kernel, brought to the pinned h_tbl by one DMA per batch
+    int *d_tbl = nullptr, *h_tbl = nullptr;
+    int tbl_ints_per_image = 0;
+    const int *tbl(int m) const { return h_tbl + (size_t)m * tbl_ints_per_image; }
     volatile uint32_t touch_sink[16] = {};
-    BucketBest *h_bbest = nullptr;   // per bucket: winner of the final pick (k_compact)
     KnnRow *d_knn = nullptr;         // k-NN rows per pair (device; read back only by mcorb_rig_get_pair_knn2)
     uint32_t *h_mlist = nullptr;     // per pair: accepted (query << 16 | train), query order (k_knn2_finalize)
     int *h_mcount = nullptr;
@@ -170,6 +176,7 @@ public:
     int ext_cap = 0;   // descriptor sets an external block may hold (mcorb_rig_match_external*)
     int device = 0;
     ResizeTap *d_taps = nullptr;
+    uint16_t *d_lut = nullptr;             // path-code tables of all levels (k_compact)
     SelectParams selp[kMaxLevels];         // per-level DistributeOctTree constants + bucketing depth
     int resize_win[2 * kMaxLevels] = {};   // per level: LDS window pitch, rows (see launch_pyramid)
     std::vector<Slot *> slots;

@@ -24,8 +24,10 @@ void launch_stage_f32(hipStream_t st, const float *src, int w, int h, int pitch_
 void launch_pyramid(hipStream_t st, uint8_t *pyr, const Geom &g, const ResizeTap *tabs, const int *win, int nimg);
 void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, uint32_t *cell_kp,
                  int *cell_cnt, int nimg);
-void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt, const Geom &g, uint32_t *sorted_dev,
-                    uint32_t *cand, int *lvl_off, int *bstart, BucketBest *bbest, int *shipped, int *overflow, int nimg);
+// tbl: device table blocks (tbl_ints(g.bucketTotal) ints per image, layout in mcorb_common.h); cand / overflow: host-mapped
+// lut: path-code tables (LevelGeom::lutx / luty)
+void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt, const Geom &g, const uint16_t *lut,
+                    uint32_t *sorted_dev, uint32_t *cand, int *tbl, int *overflow, int nimg);
 void launch_blur(hipStream_t st, const uint8_t *pyr, uint8_t *blur, const Geom &g, int nimg);
 void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, const Geom &g, const uint32_t *sel,
                      const int *nsel, int orientation, uint8_t *desc, float *angles, int nimg);

@@ -467,14 +467,31 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 }
 
 // ---------------------------------------------------------------------------
-// Candidate compaction: per-cell lists -> one contiguous list per image in
-// (level, cell row, cell col, raster) order == vToDistributeKeys order of every
-// level back to back.  One workgroup per (level, image): scan of the level's
-// cell counts in LDS, then a fully coalesced copy (binary search of the owning
-// cell per output element).  Written straight into host-mapped memory; lvl_off
-// gets nlevels+1 offsets per image.
+// Candidate compaction + quad-tree bucketing, one workgroup per (level, image).
+//
+// The per-cell lists of k_fast_cells are in (cell row, cell col, raster) order = the reference's
+// vToDistributeKeys order.  The kernel counting-sorts each level's candidates by quad-tree path code
+// (path_code(), depth g.lv[level].depth) in LDS and hands the host the bucket start offsets: the
+// host-side DistributeOctTree logic then gets every node's key count in O(1) and never has to
+// partition the candidate list itself for the first `depth` splits.  Order inside a bucket is
+// arbitrary; the selection only depends on the key SETS.  The kernel also finds each bucket's winner
+// of the reference's final pick (largest response, first one in vToDistributeKeys order on ties,
+// ORBextractor.cpp:757-775): key = response << 23 | (2^23-1 - order), order = cell * cellCap + index
+// in the cell (monotone in the vToDistributeKeys position), LDS atomicMax per bucket, and ships
+// (key, the winning candidate) per bucket, so the host never scans a node's keys unless the tree
+// went deeper than the bucketing.  The bucket tables go to a per-image table block in device memory
+// (one DMA per batch takes them to the host); the level's list itself stays on the device unless
+// the selection can need it.
+//
+// Waves walk the cells (wave w takes cells 8w .. 8w+7, then 8(w+W) ..., lane = index inside the cell) with the eight
+// cells' loads in flight together: no search for the owning cell, short dependency chains.  The path code of a
+// candidate is two LDS table reads, lutx[x] | luty[y] (path_code_tables(), mcorb_common.h).
+// (Round 1's version binary-searched the cell of every list position and ran path_code() -- a float division and
+// `depth` split iterations -- twice per candidate: 64 M vector instructions in 8192 long waves, 445 us per 128 images.
+// It was believed to be PCIe-bound; the same kernel writing to device memory took 408 us.)
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int block_exclusive_scan_1024(int v, int *wsum, int *total)
+template <int kCompactWaves>
+__device__ __forceinline__ int block_exclusive_scan(int v, int *wsum, int *total)   // 64 * kCompactWaves threads
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int s = v;
@@ -486,148 +503,136 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int v, int *wsum, int *
     if (lane == 63) wsum[wave] = s;
     __syncthreads();
     if (wave == 0) {
-        const int w = lane < 16 ? wsum[lane] : 0;
+        const int w = lane < kCompactWaves ? wsum[lane] : 0;
         int t = w;
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
+        for (int o = 1; o < kCompactWaves; o <<= 1) {
             const int u = __shfl_up(t, o);
             if (lane >= o) t += u;
         }
-        if (lane < 16) wsum[lane] = t - w;
-        if (lane == 15) *total = t;
+        if (lane < kCompactWaves) wsum[lane] = t - w;
+        if (lane == kCompactWaves - 1) *total = t;
     }
     __syncthreads();
     return wsum[wave] + s - v;
 }
 
-// Besides compacting, the kernel sorts each level's candidates by quad-tree path code
-// (path_code(), depth g.lv[level].depth) with an LDS counting sort and hands the host the bucket
-// start offsets: the host-side DistributeOctTree logic then gets every node's key count in O(1)
-// and never has to partition the candidate list itself for the first `depth` splits.
-// Order inside a bucket is arbitrary; the selection only depends on the key SETS.  The kernel also
-// finds each bucket's winner of the reference's final pick (largest response, first one in
-// vToDistributeKeys order on ties, ORBextractor.cpp:757-775): key = response << 23 | (2^23-1 - i)
-// with i the candidate's position in the unsorted level list (which IS vToDistributeKeys order),
-// LDS atomicMax per bucket, and ships (key, position in the sorted list) per bucket, so the host
-// never scans a node's keys unless the tree went deeper than the bucketing.
-__global__ __launch_bounds__(1024) void k_compact(const uint32_t *__restrict__ cell_kp, const int *__restrict__ cell_cnt,
-                                                  Geom g, uint32_t *__restrict__ sorted_dev, uint32_t *__restrict__ cand,
-                                                  int *__restrict__ lvl_off, int *__restrict__ bstart, BucketBest *__restrict__ bbest,
-                                                  int *__restrict__ shipped, int *__restrict__ overflow, int exclCap, int bktCap)
+template <int kCompactWG, int kCompactCells>
+__global__ __launch_bounds__(kCompactWG) void k_compact(const uint32_t *__restrict__ cell_kp, const int *__restrict__ cell_cnt,
+                                                        Geom g, const uint16_t *__restrict__ lut, uint32_t *__restrict__ sorted_dev,
+                                                        uint32_t *__restrict__ cand, int *__restrict__ tbl,
+                                                        int *__restrict__ overflow, int bktCap, int cellsCap)
 {
-    extern __shared__ int sh[];     // excl[exclCap] | hist[bktCap] | bkey[bktCap] | bpos[bktCap] | bval[bktCap]
-    int *excl = sh;                 // exclusive offsets of this level's cells (+1 entry for the total)
-    int *hist = sh + exclCap;
+    extern __shared__ int sh[];     // hist[bktCap] | bkey[bktCap] | bval[bktCap] | cnts[cellsCap] (u16) | tx[W0], ty[H0] (u16)
+    int *hist = sh;
     uint32_t *bkey = reinterpret_cast<uint32_t *>(hist + bktCap);
-    int *bpos = hist + 2 * bktCap;
-    uint32_t *hist_val = reinterpret_cast<uint32_t *>(hist + 3 * bktCap);   // the winner's packed candidate
-    __shared__ int wsum[16];
+    uint32_t *bval = reinterpret_cast<uint32_t *>(hist + 2 * bktCap);   // the winner's packed candidate
+    uint16_t *cnts = reinterpret_cast<uint16_t *>(hist + 3 * bktCap);    // min(count, cellCap) of this level's cells
+    constexpr int kCompactWaves = kCompactWG / 64;
+    __shared__ int wsum[kCompactWaves];
     __shared__ int s_tot, s_base, s_nz;
-    const int tid = threadIdx.x;
-    const int level = blockIdx.x, img = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int level = blockIdx.y, img = blockIdx.x;   // x runs fastest: the large levels of every image are dispatched first
     const LevelGeom &L = g.lv[level];
     const int nc = L.nCols * L.nRows;
     const int *cnt = cell_cnt + (size_t)img * g.cells;
     const int cap = g.cellCap;
     const int B = L.nBuckets;
+    const int W0 = L.maxBorderX - kMinBorder, H0 = L.maxBorderY - kMinBorder;
+    uint16_t *tx = cnts + cellsCap, *ty = tx + W0;
 
-    // candidates of all previous levels of this image
-    int s = 0, over = 0;
-    for (int c = tid; c < L.cell0; c += 1024) { const int v = cnt[c]; s += v < cap ? v : cap; }
-    (void)block_exclusive_scan_1024(s, wsum, &s_base);
-    const int base = s_base;
-    for (int b = tid; b <= B; b += 1024) { hist[b] = 0; bkey[b] = 0; bpos[b] = 0; hist_val[b] = 0; }
-    if (tid == 0) s_nz = 0;
-    __syncthreads();
-
-    // exclusive scan over this level's cells: each thread owns a contiguous run of cells
-    const int per = (nc + 1023) >> 10;
-    const int c0 = tid * per;
-    int mysum = 0;
-    for (int k = 0; k < per; k++) {
-        const int c = c0 + k;
-        if (c < nc) { int v = cnt[L.cell0 + c]; if (v > cap) { v = cap; over = 1; } mysum += v; }
+    // candidates of all previous levels of this image, and of this level
+    int s = 0, t = 0, over = 0;
+    for (int c = tid; c < L.cell0; c += kCompactWG) { const int v = cnt[c]; s += v < cap ? v : cap; }
+    for (int c = tid; c < nc; c += kCompactWG) {
+        int v = cnt[L.cell0 + c];
+        if (v > cap) { v = cap; over = 1; }
+        cnts[c] = (uint16_t)v;
+        t += v;
     }
-    int run = block_exclusive_scan_1024(mysum, wsum, &s_tot);
-    for (int k = 0; k < per; k++) {
-        const int c = c0 + k;
-        if (c < nc) { excl[c] = run; const int v = cnt[L.cell0 + c]; run += v < cap ? v : cap; }
-    }
-    int T = s_tot;
+    for (int c = nc + tid; c < nc + kCompactCells; c += kCompactWG) cnts[c] = 0;   // the walk reads whole groups of cells
+    for (int i = tid; i < W0 + H0; i += kCompactWG) tx[i] = lut[L.lutx + i];        // (ty follows tx in both places)
+    (void)block_exclusive_scan<kCompactWaves>(s, wsum, &s_base);
+    (void)block_exclusive_scan<kCompactWaves>(t, wsum, &s_tot);
+    const int base = s_base, T = s_tot;
+    for (int b = tid; b <= B; b += kCompactWG) { hist[b] = 0; bkey[b] = 0; bval[b] = 0; }
+    int *tb = tbl + (size_t)img * tbl_ints(g.bucketTotal);   // this image's table block (device memory; DMA'd to the host afterwards)
     if (tid == 0) {
-        excl[nc] = T;
-        lvl_off[(size_t)img * (kMaxLevels + 1) + level] = base;
-        if (level == g.nlevels - 1) lvl_off[(size_t)img * (kMaxLevels + 1) + g.nlevels] = base + T;
+        s_nz = 0;
+        tb[kTblLvlOff + level] = base;
+        if (level == g.nlevels - 1) tb[kTblLvlOff + g.nlevels] = base + T;
         if (base + T > g.candCap) over = 1;
     }
     if (over) atomicOr(overflow, 1);
-    if (base + T > g.candCap) T = g.candCap > base ? g.candCap - base : 0;   // flagged above; stay in bounds
     __syncthreads();
 
     const uint32_t *src = cell_kp + ((size_t)img * g.cells + L.cell0) * cap;
-    const int W0 = L.maxBorderX - kMinBorder, H0 = L.maxBorderY - kMinBorder;
-    // pass 1: histogram of path codes
-    for (int i = tid; i < T; i += 1024) {
-        int lo = 0, hi = nc;               // largest c with excl[c] <= i
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (excl[mid] <= i) lo = mid; else hi = mid;
+    // visit every candidate of the level: wave = kCompactCells consecutive cells at a time, lane = index inside the cell;
+    // cells with more than 64 candidates take extra trips
+    auto for_each = [&](auto &&fn) {
+        for (int c0 = wave * kCompactCells; c0 < nc; c0 += kCompactWaves * kCompactCells) {
+            int n[kCompactCells];
+            uint32_t p[kCompactCells];
+#pragma unroll
+            for (int u = 0; u < kCompactCells; u++) {
+                n[u] = cnts[c0 + u];
+                p[u] = lane < n[u] ? src[(size_t)(c0 + u) * cap + lane] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kCompactCells; u++) {
+                if (lane < n[u]) fn(p[u], (c0 + u) * cap + lane);
+                for (int k = lane + 64; k < n[u]; k += 64) fn(src[(size_t)(c0 + u) * cap + k], (c0 + u) * cap + k);
+            }
         }
-        const uint32_t p = src[(size_t)lo * cap + (i - excl[lo])];
-        const uint32_t code = path_code(cand_x(p), cand_y(p), W0, H0, L.nIni, L.hX, L.depth);
+    };
+    // pass 1: histogram of path codes + per-bucket winner key
+    for_each([&](uint32_t p, int order) {
+        const uint32_t code = (uint32_t)tx[cand_x(p)] | (uint32_t)ty[cand_y(p)];
         atomicAdd(&hist[code], 1);
-        atomicMax(&bkey[code], ((uint32_t)cand_resp(p) << 23) | (uint32_t)(kPickOrderMask - i));
-    }
+        atomicMax(&bkey[code], ((uint32_t)cand_resp(p) << 23) | (uint32_t)(kPickOrderMask - order));
+    });
     __syncthreads();
     // bucket starts: exclusive scan of the histogram (each thread owns a contiguous run of buckets)
     {
-        const int bper = (B + 1023) >> 10;
+        const int bper = (B + kCompactWG - 1) / kCompactWG;
         const int b0 = tid * bper;
         int bs = 0, nzl = 0;
         for (int k = 0; k < bper; k++) if (b0 + k < B) { bs += hist[b0 + k]; nzl += hist[b0 + k] > 0; }
         if (nzl) atomicAdd(&s_nz, nzl);
-        int brun = block_exclusive_scan_1024(bs, wsum, &s_tot);
+        int brun = block_exclusive_scan<kCompactWaves>(bs, wsum, &s_tot);
         for (int k = 0; k < bper; k++) {
             if (b0 + k < B) { const int v = hist[b0 + k]; hist[b0 + k] = brun; brun += v; }
         }
         if (tid == 0) hist[B] = T;
     }
     __syncthreads();
-    int *bs_out = bstart + (size_t)img * g.bucketTotal + L.bucket0;
-    for (int b = tid; b <= B; b += 1024) bs_out[b] = hist[b];
+    int *bs_out = tb + kTblHead + L.bucket0;
+    for (int b = tid; b <= B; b += kCompactWG) bs_out[b] = hist[b];
     __syncthreads();
     // pass 2: scatter into bucket order (device memory), hist[] now counts up from each bucket's start
     uint32_t *sd = sorted_dev + (size_t)img * g.candCap + base;
-    for (int i = tid; i < T; i += 1024) {
-        int lo = 0, hi = nc;
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (excl[mid] <= i) lo = mid; else hi = mid;
-        }
-        const uint32_t p = src[(size_t)lo * cap + (i - excl[lo])];
-        const uint32_t code = path_code(cand_x(p), cand_y(p), W0, H0, L.nIni, L.hX, L.depth);
+    const int room = g.candCap - base;   // (the device list is sized for the worst case; stay in bounds regardless)
+    for_each([&](uint32_t p, int order) {
+        const uint32_t code = (uint32_t)tx[cand_x(p)] | (uint32_t)ty[cand_y(p)];
         const int slot = atomicAdd(&hist[code], 1);
-        sd[slot] = p;
-        if (bkey[code] == (((uint32_t)cand_resp(p) << 23) | (uint32_t)(kPickOrderMask - i))) {   // keys are unique
-            bpos[code] = slot;
-            hist_val[code] = p;
-        }
-    }
+        if (slot < room) sd[slot] = p;
+        if (bkey[code] == (((uint32_t)cand_resp(p) << 23) | (uint32_t)(kPickOrderMask - order))) bval[code] = p;   // keys are unique
+    });
     __syncthreads();   // the workgroup's own global stores are visible to it after the barrier
-    BucketBest *bb_out = bbest + (size_t)img * g.bucketTotal + L.bucket0;
-    for (int b = tid; b < B; b += 1024) bb_out[b] = BucketBest{bkey[b], (uint32_t)bpos[b], hist_val[b]};
+    uint2 *bb_out = reinterpret_cast<uint2 *>(tb + kTblHead + g.bucketTotal) + L.bucket0;   // BucketWin {key, val}
+    for (int b = tid; b < B; b += kCompactWG) bb_out[b] = uint2{bkey[b], bval[b]};
     // The list itself goes over PCIe only when the host can need it: DistributeOctTree divides a depth-D node (one
     // bucket) only after every node reached depth D with fewer than N nodes in total, and at that point the node count
-    // equals the number of non-empty buckets.  With nz >= N the host works from bstart/bbest alone.
+    // equals the number of non-empty buckets.  With nz >= N the host works from the bucket tables alone.
     bool ship = s_nz < L.quota;
     if (ship && base + T > g.hostCandCap) {   // the host copy is smaller than the device list: tell the host instead of truncating
         ship = false;
         if (tid == 0) atomicOr(overflow, 1);
     }
-    if (tid == 0) shipped[(size_t)img * kMaxLevels + level] = ship ? 1 : 0;
+    if (tid == 0) tb[kTblShipped + level] = ship ? 1 : 0;
     if (ship) {
         uint32_t *dst = cand + (size_t)img * g.hostCandCap + base;
-        for (int i = tid; i < T; i += 1024) dst[i] = sd[i];   // coalesced copy-out into host-mapped memory
+        for (int i = tid; i < T; i += kCompactWG) dst[i] = sd[i];   // coalesced copy-out into host-mapped memory
     }
 }
 
@@ -1191,18 +1196,29 @@ void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, i
     else hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, cell_kp, cell_cnt);
 }
 
-void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt, const Geom &g, uint32_t *sorted_dev,
-                    uint32_t *cand, int *lvl_off, int *bstart, BucketBest *bbest, int *shipped, int *overflow, int nimg)
+void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt, const Geom &g, const uint16_t *lut,
+                    uint32_t *sorted_dev, uint32_t *cand, int *tbl, int *overflow, int nimg)
 {
-    int maxc = 1, maxb = 1;
+    int maxb = 1, maxc = 1, maxwh = 2;
     for (int l = 0; l < g.nlevels; l++) {
-        maxc = maxc > g.lv[l].nCols * g.lv[l].nRows ? maxc : g.lv[l].nCols * g.lv[l].nRows;
         maxb = maxb > g.lv[l].nBuckets ? maxb : g.lv[l].nBuckets;
+        maxc = maxc > g.lv[l].nCols * g.lv[l].nRows ? maxc : g.lv[l].nCols * g.lv[l].nRows;
+        const int wh = (g.lv[l].maxBorderX - kMinBorder) + (g.lv[l].maxBorderY - kMinBorder);
+        maxwh = maxwh > wh ? maxwh : wh;
     }
-    const int exclCap = (maxc + 1 + 3) & ~3;
     const int bktCap = (maxb + 1 + 3) & ~3;
-    hipLaunchKernelGGL(k_compact, dim3(g.nlevels, nimg), dim3(1024), (size_t)(exclCap + 4 * bktCap) * sizeof(int), st, cell_kp,
-                       cell_cnt, g, sorted_dev, cand, lvl_off, bstart, bbest, shipped, overflow, exclCap, bktCap);
+    static const int wg_env = getenv("MCORB_COMPACT_WG") ? atoi(getenv("MCORB_COMPACT_WG")) : 0;
+    static const int cells_env = getenv("MCORB_COMPACT_CELLS") ? atoi(getenv("MCORB_COMPACT_CELLS")) : 0;
+    const int wg = wg_env == 1024 || wg_env == 256 ? wg_env : 512, cellsInFlight = cells_env == 4 ? 4 : 8;
+    const int cellsCap = (maxc + 8 + 7) & ~7;   // u16 entries, a multiple of 8
+    const size_t lds = (size_t)(3 * bktCap) * sizeof(int) + (size_t)(cellsCap + maxwh + 8) * sizeof(uint16_t);
+    const dim3 grid(nimg, g.nlevels);
+#define MCORB_COMPACT_LAUNCH(WG_, C_) \
+    hipLaunchKernelGGL((k_compact<WG_, C_>), grid, dim3(WG_), lds, st, cell_kp, cell_cnt, g, lut, sorted_dev, cand, tbl, overflow, bktCap, cellsCap)
+    if (wg == 1024) { if (cellsInFlight == 4) MCORB_COMPACT_LAUNCH(1024, 4); else MCORB_COMPACT_LAUNCH(1024, 8); }
+    else if (wg == 256) { if (cellsInFlight == 4) MCORB_COMPACT_LAUNCH(256, 4); else MCORB_COMPACT_LAUNCH(256, 8); }
+    else { if (cellsInFlight == 4) MCORB_COMPACT_LAUNCH(512, 4); else MCORB_COMPACT_LAUNCH(512, 8); }
+#undef MCORB_COMPACT_LAUNCH
 }
 
 void launch_blur(hipStream_t st, const uint8_t *pyr, uint8_t *blur, const Geom &g, int nimg)

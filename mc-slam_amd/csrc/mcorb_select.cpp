@@ -119,7 +119,11 @@ static bool divide(SelectScratch::Impl &S, const uint32_t *cand, const int *bsta
     return true;
 }
 
-int select_octree(const uint32_t *cand, const int *bstart, const BucketBest *bbest, int n, const SelectParams &P, int *out_idx,
+static inline int win_pos(const BucketBest &b) { return (int)b.pos; }
+static inline int win_pos(const BucketWin &) { return -1; }
+
+template <typename BB>
+int select_octree(const uint32_t *cand, const int *bstart, const BB *bbest, int n, const SelectParams &P, int *out_idx,
                   uint32_t *out_val, SelectScratch &scratch)
 {
     SelectScratch::Impl &S = *scratch.impl;
@@ -214,13 +218,14 @@ int select_octree(const uint32_t *cand, const int *bstart, const BucketBest *bbe
             // the node is a run of buckets whose winners the GPU already found: the largest key wins
             // (a single-key node is the one non-empty bucket of its run)
             const int shift = 2 * (D - nd.d);
-            const BucketBest *bb = bbest + ((size_t)nd.code << shift);
+            const BB *bb = bbest + ((size_t)nd.code << shift);
             const int nb = 1 << shift;
-            uint32_t bestKey = 0, bestPos = 0, bestVal = 0;
+            uint32_t bestKey = 0, bestVal = 0;
+            int bestPos = -1;
             for (int b = 0; b < nb; b++)
-                if (bb[b].key > bestKey) { bestKey = bb[b].key; bestPos = bb[b].pos; bestVal = bb[b].val; }
+                if (bb[b].key > bestKey) { bestKey = bb[b].key; bestPos = win_pos(bb[b]); bestVal = bb[b].val; }
             out_val[m] = bestVal;
-            out_idx[m++] = (int)bestPos;
+            out_idx[m++] = bestPos;
             continue;
         }
         if (nd.cnt == 1) { out_val[m] = cand[S.arena[nd.beg]]; out_idx[m++] = S.arena[nd.beg]; continue; }
@@ -241,6 +246,11 @@ int select_octree(const uint32_t *cand, const int *bstart, const BucketBest *bbe
     }
     return m;
 }
+
+template int select_octree<BucketBest>(const uint32_t *, const int *, const BucketBest *, int, const SelectParams &, int *, uint32_t *,
+                                       SelectScratch &);
+template int select_octree<BucketWin>(const uint32_t *, const int *, const BucketWin *, int, const SelectParams &, int *, uint32_t *,
+                                      SelectScratch &);
 
 // CPU statement of what k_compact does on the GPU for one level (used by the host-only test hook):
 // counting sort of the candidates by path code, bucket starts out.

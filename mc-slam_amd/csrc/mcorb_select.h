@@ -34,7 +34,10 @@ SelectParams make_select_params(int minX, int maxX, int minY, int maxY, int N, i
 // the level is too tall for a root node (the reference divides by zero there).
 // out_val: the retained candidates themselves (packed).  cand may be null when the level's list was not shipped
 // (k_compact ships it only if fewer than N buckets are non-empty); -3 if the tree then wanted to go deeper.
-int select_octree(const uint32_t *cand, const int *bstart, const BucketBest *bbest, int n, const SelectParams &P, int *out_idx,
+// BB = BucketWin (what the GPU ships: key + candidate) or BucketBest (host statement, also the position; out_idx of a
+// bucket-resolved node is -1 with BucketWin).
+template <typename BB>
+int select_octree(const uint32_t *cand, const int *bstart, const BB *bbest, int n, const SelectParams &P, int *out_idx,
                   uint32_t *out_val, SelectScratch &scratch);
 
 // host statement of k_compact's counting sort for one level (test hook only)

@@ -50,6 +50,23 @@ static int run_case(std::mt19937 &rng, int W, int H, int N, int npts, int box)
     return 0;
 }
 
+// k_compact's table form of the path code: lutx[x] | luty[y] must equal path_code(x, y) for EVERY candidate position
+static int run_path_tables(int W, int H, int N)
+{
+    const mcorb::SelectParams P = mcorb::make_select_params(16, W - 16, 16, H - 16, N, 0, 0);
+    if (P.nIni < 1) return 0;
+    const int W0 = W - 32, H0 = H - 32;
+    std::vector<uint16_t> tx(W0), ty(H0);
+    mcorb::path_code_tables(W0, H0, P.nIni, P.hX, P.depth, tx.data(), ty.data());
+    for (int y = 0; y < H0; y++)
+        for (int x = 0; x < W0; x++)
+            if (((uint32_t)tx[x] | (uint32_t)ty[y]) != mcorb::path_code(x, y, W0, H0, P.nIni, P.hX, P.depth)) {
+                fprintf(stderr, "path code table mismatch at (%d, %d), %dx%d N %d\n", x, y, W, H, N);
+                return 1;
+            }
+    return 0;
+}
+
 extern "C" int mcorb_synth_rig_frame(uint32_t frame, int ncams, int cam, int w, int h, uint8_t *out, int stride);
 
 // the oracle itself (the checker of every parity claim) through the same sanitizers: extraction, matching, track merge
@@ -84,6 +101,9 @@ int main()
                           {1920, 1080, 434, 20000, 0}, {200, 120, 30, 1, 0}, {752, 480, 300, 2, 0}};
     for (auto &c : cfg)
         for (int rep = 0; rep < 3; rep++, cases++) bad += run_case(rng, c[0], c[1], c[2], c[3], c[4]);
+    const int geo[][3] = {{1280, 720, 434}, {1067, 600, 362}, {357, 201, 122}, {1920, 1080, 434}, {640, 480, 5}, {536, 301, 122},
+                          {4000, 300, 2000}, {300, 400, 30}, {803, 601, 3000}};
+    for (auto &q : geo) bad += run_path_tables(q[0], q[1], q[2]);
     bad += run_oracle(320, 240, 500);
     bad += run_oracle(411, 305, 800);
     printf("select_sanitize cases=%d bad=%d\n", cases, bad);
