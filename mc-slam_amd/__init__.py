@@ -365,7 +365,9 @@ class ORBextractor:
         for a in range(len(i_A)):
             d1 = float(dist[a, 0])
             d2 = float(dist[a, 1]) if idx[a, 1] >= 0 else 1e9
-            if d1 <= TH_LOW and d1 / d2 <= self.max_neighbor_ratio:
+            # best_dist_1 / best_dist_2 is a double division in the reference (:1264): 0 / 0 (duplicate descriptors) is NaN
+            # there, the comparison is false and the feature is skipped
+            if d1 <= TH_LOW and d2 > 0 and d1 / d2 <= self.max_neighbor_ratio:
                 idx_B = int(i_B[idx[a, 0]])
                 if idx_B not in mB:
                     mB.append(idx_B)

@@ -14,7 +14,8 @@ struct mcorb_extractor {
     Rig *rig = nullptr;   // rebuilt when the image size changes
     int w = 0, h = 0;
     // scratch for mcorb_knn2 on host arrays
-    uint8_t *d_desc = nullptr;
+    uint8_t *d_desc = nullptr, *d_exp = nullptr;
+    int *d_lcounts = nullptr;
     uint2 *d_part = nullptr;
     KnnRow *h_rows = nullptr;
     uint32_t *h_mlist = nullptr;
@@ -472,6 +473,9 @@ static void free_knn_scratch(mcorb_t *e)
 {
     if (e->d_desc) (void)hipFree(e->d_desc);
     if (e->d_part) (void)hipFree(e->d_part);
+    if (e->d_exp) (void)hipFree(e->d_exp);
+    if (e->d_lcounts) (void)hipFree(e->d_lcounts);
+    e->d_exp = nullptr; e->d_lcounts = nullptr;
     if (e->h_rows) (void)hipHostFree(e->h_rows);
     if (e->h_mlist) (void)hipHostFree(e->h_mlist);
     if (e->h_mcount) (void)hipHostFree(e->h_mcount);
@@ -629,6 +633,8 @@ static int knn2_host_arrays(mcorb_t *e, const uint8_t *q, int nq, const uint8_t 
         const int nchunks = (need + kKnnChunk - 1) / kKnnChunk;
         HIPCHK(hipMalloc((void **)&e->d_desc, (size_t)2 * need * 32));
         HIPCHK(hipMalloc((void **)&e->d_part, (size_t)nchunks * need * sizeof(uint2)));
+        HIPCHK(hipMalloc((void **)&e->d_exp, (size_t)2 * need * kKnnExpandBytes));
+        HIPCHK(hipMalloc((void **)&e->d_lcounts, 2 * sizeof(int)));
         HIPCHK(hipHostMalloc((void **)&e->h_rows, (size_t)need * sizeof(KnnRow), hipHostMallocMapped));
         HIPCHK(hipHostMalloc((void **)&e->h_mlist, (size_t)need * sizeof(uint32_t), hipHostMallocMapped));
         HIPCHK(hipHostMalloc((void **)&e->h_mcount, sizeof(int), hipHostMallocMapped));
@@ -641,7 +647,8 @@ static int knn2_host_arrays(mcorb_t *e, const uint8_t *q, int nq, const uint8_t 
     e->h_counts[0] = nq;
     e->h_counts[1] = nt;
     e->h_pair[0] = int2{0, 1};
-    launch_knn2(nullptr, e->d_desc, e->h_counts, e->h_pair, 1, e->kc, e->d_part, thr, ratio, e->h_rows, e->h_mlist, e->h_mcount, nullptr);
+    launch_knn2(nullptr, e->d_desc, e->h_counts, nullptr, 2, e->h_pair, 1, e->kc, e->d_exp, e->d_lcounts, e->d_part, thr, ratio, e->h_rows,
+                e->h_mlist, e->h_mcount, nullptr, nullptr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(nullptr));
     return MCORB_OK;

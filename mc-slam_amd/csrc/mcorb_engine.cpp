@@ -424,6 +424,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         const bool blocking = sync_env ? !strcmp(sync_env, "block") : nslots > 8;
         HIPCHK(hipEventCreateWithFlags(&s->ev_x, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_c, hipEventDefault));
+        HIPCHK(hipEventCreateWithFlags(&s->ev_e, hipEventDefault));
         for (int e = 0; e < 12; e++) {
             const bool waited = e == 3 || e == 10 || e == 11;
             HIPCHK(hipEventCreateWithFlags(&s->ev[e], waited && blocking ? hipEventBlockingSync : hipEventDefault));
@@ -443,6 +444,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         HIPCHK(hipMemset(s->d_desc, 0, M * geom.kcap * 32));
         TRY(dev_alloc(&s->d_angles, M * geom.kcap));
         TRY(dev_alloc(&s->d_part, (size_t)npairs_max * nchunks * geom.kcap));
+        TRY(dev_alloc(&s->d_exp, M * geom.kcap * (size_t)kKnnExpandBytes));
+        TRY(dev_alloc(&s->d_lcounts, M));
         TRY(host_alloc(&s->h_cand, M * geom.hostCandCap));
         TRY(host_alloc(&s->h_overflow, 16));
         TRY(dev_alloc(&s->d_knn, (size_t)npairs_max * geom.kcap));
@@ -450,7 +453,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         TRY(host_alloc(&s->h_mcount, (size_t)npairs_max));
         {
             const size_t o_nsel = (size_t)ext_cap * sizeof(int);
-            const size_t o_pairs = align_up(o_nsel + M * sizeof(int), 64);
+            const size_t o_setmap = align_up(o_nsel + M * sizeof(int), 64);
+            const size_t o_pairs = align_up(o_setmap + M * sizeof(int), 64);
             const size_t o_sel = align_up(o_pairs + (size_t)npairs_max * sizeof(int2), 64);
             s->ctrl_pairs_end = o_sel;
             s->ctrl_bytes = o_sel + M * geom.kcap * sizeof(uint32_t);
@@ -459,6 +463,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
             HIPCHK(hipMemset(s->d_ctrl, 0, s->ctrl_bytes));
             s->h_extcounts = (int *)s->h_ctrl;            s->d_extcounts = (int *)s->d_ctrl;
             s->h_nsel = (int *)(s->h_ctrl + o_nsel);      s->d_nsel = (int *)(s->d_ctrl + o_nsel);
+            s->h_setmap = (int *)(s->h_ctrl + o_setmap);  s->d_setmap = (int *)(s->d_ctrl + o_setmap);
             s->h_pairs = (int2 *)(s->h_ctrl + o_pairs);   s->d_pairs = (int2 *)(s->d_ctrl + o_pairs);
             s->h_sel = (uint32_t *)(s->h_ctrl + o_sel);   s->d_sel = (uint32_t *)(s->d_ctrl + o_sel);
         }
@@ -499,7 +504,7 @@ Rig::~Rig()
         if (s->st_copy) (void)hipStreamSynchronize(s->st_copy);
         if (s->st_dma) (void)hipStreamSynchronize(s->st_dma);
         (void)hipFree(s->d_pyr); (void)hipFree(s->d_blur); (void)hipFree(s->d_desc); (void)hipFree(s->d_cellkp);
-        (void)hipFree(s->d_cellcnt); (void)hipFree(s->d_sorted); (void)hipFree(s->d_tbl); (void)hipHostFree(s->h_tbl); (void)hipFree(s->d_angles); (void)hipFree(s->d_part); (void)hipFree(s->d_f32);
+        (void)hipFree(s->d_cellcnt); (void)hipFree(s->d_sorted); (void)hipFree(s->d_tbl); (void)hipHostFree(s->h_tbl); (void)hipFree(s->d_angles); (void)hipFree(s->d_part); (void)hipFree(s->d_exp); (void)hipFree(s->d_lcounts); (void)hipFree(s->d_f32);
         (void)hipHostFree(s->h_cand); (void)hipHostFree(s->h_overflow);
         (void)hipFree(s->d_knn); (void)hipHostFree(s->h_mlist); (void)hipHostFree(s->h_mcount); (void)hipHostFree(s->h_ctrl); (void)hipFree(s->d_ctrl);
         (void)hipHostFree(s->h_stage);
@@ -507,6 +512,7 @@ Rig::~Rig()
         for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
         if (s->ev_x) (void)hipEventDestroy(s->ev_x);
         if (s->ev_c) (void)hipEventDestroy(s->ev_c);
+        if (s->ev_e) (void)hipEventDestroy(s->ev_e);
         if (s->st && !s->shared_st) (void)hipStreamDestroy(s->st);
         if (s->st_copy) (void)hipStreamDestroy(s->st_copy);
         if (s->st_dma) (void)hipStreamDestroy(s->st_dma);
@@ -840,11 +846,16 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     launch_describe(s.st, s.d_pyr, s.d_blur, geom, s.d_sel, s.d_nsel, params.orientation, s.d_desc, s.d_angles, nimg);
     HIPCHK(hipEventRecord(s.ev[6], s.st));
     // descriptors go back to the host on the side stream (DMA) while the matcher already runs
-    HIPCHK(hipStreamWaitEvent(s.st_dma, s.ev[6], 0));
+    static const bool d2h_late = getenv("MCORB_D2H_LATE") != nullptr;   // experiment: copy after the k-NN instead of beside it
+    if (!d2h_late || !then_match) HIPCHK(hipStreamWaitEvent(s.st_dma, s.ev[6], 0));
+    if (then_match && d2h_late) {
+        TRY(enqueue_match(s, j, true));
+        HIPCHK(hipStreamWaitEvent(s.st_dma, s.ev[9], 0));
+    }
     HIPCHK(hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)nimg * geom.kcap * 32, hipMemcpyDeviceToHost, s.st_dma));
     if (params.orientation)
         HIPCHK(hipMemcpyAsync(s.h_angles, s.d_angles, (size_t)nimg * geom.kcap * sizeof(float), hipMemcpyDeviceToHost, s.st_dma));
-    if (then_match) TRY(enqueue_match(s, j, true));
+    if (then_match && !d2h_late) TRY(enqueue_match(s, j, true));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s.ev[10], s.st));
     HIPCHK(hipEventRecord(s.ev[11], s.st_dma));
@@ -897,10 +908,12 @@ int Rig::prepare_match(Slot &s, const Job &j)
         for (int i = 0; i < j.nframes * C; i++) { s.match_sets[i] = i; s.match_counts[i] = s.h_nsel[i]; }
     }
     s.nframes_done = j.nframes;
+    // the k-NN works on LOCAL set indices (frame * cameras + camera): k_expand gathers set setmap[i] into local slot i
+    for (int i = 0; i < j.nframes * C; i++) s.h_setmap[i] = s.match_sets[i];
     int p = 0;
     for (int f = 0; f < j.nframes; f++)
         for (int a = 0; a < C - 1; a++)
-            for (int b = a + 1; b < C; b++) s.h_pairs[p++] = int2{s.match_sets[f * C + a], s.match_sets[f * C + b]};
+            for (int b = a + 1; b < C; b++) s.h_pairs[p++] = int2{f * C + a, f * C + b};
     s.npairs_done = p;
     return MCORB_OK;
 }
@@ -922,8 +935,9 @@ int Rig::enqueue_match(Slot &s, const Job &j, bool ctrl_on_device)
     if (s.npairs_done == 0) return MCORB_OK;
     const bool ext = j.ext_desc != nullptr;
     HIPCHK(hipEventRecord(s.ev[7], s.st));
-    launch_knn2(s.st, ext ? (const uint8_t *)j.ext_desc : s.d_desc, ext ? s.d_extcounts : s.d_nsel, s.d_pairs,
-                s.npairs_done, geom.kcap, s.d_part, j.dist_thresh, j.ratio, s.d_knn, s.h_mlist, s.h_mcount, s.ev[8]);
+    launch_knn2(s.st, ext ? (const uint8_t *)j.ext_desc : s.d_desc, ext ? s.d_extcounts : s.d_nsel, s.d_setmap, s.nframes_done * ncams,
+                s.d_pairs, s.npairs_done, geom.kcap, s.d_exp, s.d_lcounts, s.d_part, j.dist_thresh, j.ratio, s.d_knn, s.h_mlist,
+                s.h_mcount, s.ev_e, s.ev[8]);
     HIPCHK(hipEventRecord(s.ev[9], s.st));
     HIPCHK(hipGetLastError());
     return MCORB_OK;
@@ -1020,7 +1034,7 @@ int Rig::finish_match(Slot &s, const Job &j)
     if (s.npairs_done > 0) {
         float m = 0;
         (void)hipEventElapsedTime(&m, s.ev[7], s.ev[9]); s.timing[3] = m * 1000.f;
-        (void)hipEventElapsedTime(&m, s.ev[7], s.ev[8]); s.timing[7] = m * 1000.f;   // k_knn2
+        (void)hipEventElapsedTime(&m, s.ev_e, s.ev[8]); s.timing[7] = m * 1000.f;   // k_knn2 (k_expand in front of it: timing[3] - [7] - finalize)
     }
     return MCORB_OK;
 }

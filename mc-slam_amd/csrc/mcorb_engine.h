@@ -93,6 +93,7 @@ struct Slot {
     hipStream_t st = nullptr, st_copy = nullptr, st_dma = nullptr;   // compute; PCIe-bound compaction kernel; D2H copies only
     hipEvent_t ev_x = nullptr;   // cross-stream hand-offs with the caller's streams (export / external match)
     hipEvent_t ev_c = nullptr;   // k_compact finished (the table DMA follows it on the side stream)
+    hipEvent_t ev_e = nullptr;   // k_expand finished (k_knn2 follows)
     hipEvent_t ev[12] = {};  // 0 start, 1 pyramid done, 2 FAST done, 3 compact done, 4 blur done, 5/6 describe(+D2H), 7 knn2 start, 8 knn2 done, 9 finalize done
     // device
     uint8_t *d_pyr = nullptr, *d_blur = nullptr, *d_desc = nullptr;
@@ -100,6 +101,8 @@ struct Slot {
     int *d_cellcnt = nullptr;
     float *d_angles = nullptr, *d_f32 = nullptr;
     uint2 *d_part = nullptr;
+    uint8_t *d_exp = nullptr;        // descriptors of the sets being matched, expanded to +-64 int8 in MFMA fragment order (k_expand)
+    int *d_lcounts = nullptr;        // their clamped counts, local set order
     size_t f32_bytes = 0;
     // host, device-mapped (kernels write/read these directly over PCIe)
     uint32_t *h_cand = nullptr;
@@ -114,13 +117,13 @@ struct Slot {
     uint32_t *h_mlist = nullptr;     // per pair: accepted (query << 16 | train), query order (k_knn2_finalize)
     int *h_mcount = nullptr;
     // control block: one pinned host buffer + one device mirror, copied with a single
-    // hipMemcpyAsync: [extcounts ext_cap ints][nsel][pairs][sel]
+    // hipMemcpyAsync: [extcounts ext_cap ints][nsel][setmap][pairs][sel]
     uint8_t *h_ctrl = nullptr, *d_ctrl = nullptr;
     size_t ctrl_pairs_end = 0, ctrl_bytes = 0;
-    int *h_extcounts = nullptr, *h_nsel = nullptr;
+    int *h_extcounts = nullptr, *h_nsel = nullptr, *h_setmap = nullptr;
     int2 *h_pairs = nullptr;
     uint32_t *h_sel = nullptr;
-    int *d_extcounts = nullptr, *d_nsel = nullptr;
+    int *d_extcounts = nullptr, *d_nsel = nullptr, *d_setmap = nullptr;
     int2 *d_pairs = nullptr;
     uint32_t *d_sel = nullptr;
     // host, pinned

@@ -5,7 +5,8 @@
 
 namespace mcorb {
 
-constexpr int kKnnChunk = 256;   // train descriptors staged in LDS per workgroup (8 KiB)
+constexpr int kKnnChunk = 4096;  // train descriptors per k-NN partial (one workgroup column); the in-chunk index must stay below 8192
+constexpr int kKnnExpandBytes = 256;   // bytes of one descriptor expanded to +-64 int8 (k_expand)
 
 // one row of the knnMatch(k=2) table, 8 bytes so the PCIe write-back stays small:
 // idx = trainIdx0 | trainIdx1 << 16 (0xffff = absent), d = dist0 | dist1 << 9 | accept << 18
@@ -31,8 +32,12 @@ void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt
 void launch_blur(hipStream_t st, const uint8_t *pyr, uint8_t *blur, const Geom &g, int nimg);
 void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, const Geom &g, const uint32_t *sel,
                      const int *nsel, int orientation, uint8_t *desc, float *angles, int nimg);
-void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const int2 *pairs, int npairs, int kcap,
-                 uint2 *part, float dist_thresh, float ratio, KnnRow *out, uint32_t *mlist, int *mcount, hipEvent_t ev_mid);
+// desc / counts: `kcap`-strided bit descriptors and their counts; setmap[i] (null = identity) = the set that becomes local
+// set i, i < nsets; pairs: (query, train) LOCAL set indices; expanded: nsets * kcap * kKnnExpandBytes bytes of scratch;
+// lcounts: nsets ints (receives the clamped counts); part: npairs * ceil(kcap / kKnnChunk) * kcap partials
+void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const int *setmap, int nsets, const int2 *pairs, int npairs,
+                 int kcap, void *expanded, int *lcounts, uint2 *part, float dist_thresh, float ratio, KnnRow *out, uint32_t *mlist,
+                 int *mcount, hipEvent_t ev_exp, hipEvent_t ev_mid);   // events (optional): after k_expand, after k_knn2
 
 void launch_bow_best2(hipStream_t st, const uint8_t *desc, const int *sets, int kcap, int ncams, const float *yv,
                       const int *slot_of, const int2 *node_range, const int *node_feats, const int *nfeat, int4 *out);

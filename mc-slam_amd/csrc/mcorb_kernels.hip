@@ -941,33 +941,182 @@ __global__ __launch_bounds__(256) void k_describe_oriented(const uint8_t *__rest
 }
 
 // ---------------------------------------------------------------------------
-// All-pairs Hamming k-NN, k = 2 (BFMatcher knnMatch, MultiCameraFrame.cpp:
-// 1053-1055).  One query per lane (4 x u64 in registers); a chunk of train
-// descriptors is staged in LDS and every lane reads the same descriptor
-// (broadcast ds_read_b128).  (distance << 16 | trainIdx) as one u32 key makes
-// "two smallest keys" exactly knnMatch's order, including its lowest-index
-// tie-break, so chunks can be reduced in any order.
+// All-pairs Hamming k-NN, k = 2 (BFMatcher knnMatch, MultiCameraFrame.cpp:1053-1055) on the matrix cores.
+//
+// Hamming(a, b) over 256 bits is a dense contraction: with every bit expanded to an int8 of +-64,
+//   dot(Ea, Eb) = 4096 * (256 - 2 * hamming)            (exact in the i32 accumulator, |dot| <= 2^20)
+// so one v_mfma_i32_32x32x32_i8 tile (32 trains x 32 queries, 8 K-steps of 32 bits) yields 1024 distances in 256
+// cycles, against 78 cycles per 64 distances for the xor + v_bcnt formulation (19.5 vector instructions each,
+// which ran at 90 % of ITS ceiling in round 1).  A ninth K-step adds 8191 - trainIndex (as 1 * (i & 63) +
+// 64 * (i >> 6)), smaller than one distance step of 8192, so the accumulator IS the sort key:
+//   key = 8192 * (128 - hamming) + (8191 - trainIndex)   larger key <=> smaller (distance, index),
+// i.e. knnMatch's order including its lowest-index tie-break, with no per-element index arithmetic.  Every lane owns
+// one query column (16 train rows of it per tile): the running two largest keys cost v_max + v_med3 per element.
+// Results are converted back to the (distance << 16 | trainIndex) partials k_knn2_finalize merges.
+//
+// k_expand writes the +-64 bytes in MFMA FRAGMENT ORDER, [tile of 32 descriptors][K-step][lane = half * 32 + row][16 B],
+// so that a wave's A or B operand of one K-step is 1 KiB of consecutive memory: query fragments are loaded straight
+// into registers (coalesced), train tiles are copied linearly into LDS and read back conflict-free with ds_read_b128.
+// The lane -> k mapping inside a fragment is the same for A and B, whatever the hardware's order of k: the sum over
+// k pairs the same bytes.
 // ---------------------------------------------------------------------------
-// popcount(x) + acc in one instruction; chaining the eight words of a 256-bit XOR through the
-// accumulator operand saves the separate adds the compiler otherwise emits
-__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int kKnnQT = 2;                  // query tiles (32 queries each) per wave
+constexpr int kKnnWaves = 4;               // waves per workgroup: 256 queries
+constexpr int kTileU4 = 8 * 64;            // uint4 elements of one expanded tile (8 K-steps x 64 lanes)
+
+// bit descriptors -> +-64 bytes in fragment order; also gathers the sets a match refers to (setmap) into local order
+// and writes their clamped counts.  One thread per descriptor (two coalesced 16-byte loads, sixteen 16-byte stores that
+// form 512 contiguous bytes across the 32 lanes of a tile); grid (kcap / 256, local sets)
+__global__ __launch_bounds__(256) void k_expand(const uint8_t *__restrict__ desc, const int *__restrict__ counts,
+                                                const int *__restrict__ setmap, int kcap, uint4 *__restrict__ E,
+                                                int *__restrict__ lcounts)
 {
-    uint32_t r;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    const int i = blockIdx.y;
+    const int src = setmap ? setmap[i] : i;
+    const int n = min(max(counts[src], 0), kcap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) lcounts[i] = n;
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= n) return;   // rows >= n of the last tile are never written: the k-NN kernel masks them
+    const uint4 *dp = reinterpret_cast<const uint4 *>(desc + ((size_t)src * kcap + d) * 32);
+    const uint4 lo = dp[0], hi = dp[1];
+    const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint4 *out = E + ((size_t)i * (kcap / 32) + (d >> 5)) * kTileU4 + (d & 31);
+#pragma unroll
+    for (int sh = 0; sh < 16; sh++) {                 // K-step * 2 + half: bits [16 sh, 16 sh + 16)
+        const uint32_t bits = (w[sh >> 1] >> (16 * (sh & 1))) & 0xffffu;
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            // nibble -> four bytes: bit j lands on bit 8j (the four shifted copies do not overlap), then 0x80 / 0x00 -> +64 / -64
+            const uint32_t y = (((bits >> (4 * q)) & 15u) * 0x00204081u) & 0x01010101u;
+            o[q] = (y << 7) ^ 0xC0C0C0C0u;
+        }
+        out[(sh >> 1) * 64 + (sh & 1) * 32] = uint4{o[0], o[1], o[2], o[3]};
+    }
+}
+
+__device__ __forceinline__ int med3_i32(int a, int b, int c)
+{
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-__device__ __forceinline__ uint32_t hamming256(const ulonglong4 &a, const ulonglong4 &b)
+
+// kKnnStageTiles: train tiles per LDS stage (8 KiB each), double buffered
+template <int kKnnStageTiles>
+__global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint4 *__restrict__ E, const int *__restrict__ lcounts,
+                                                        const int2 *__restrict__ pairs, int kcap, int nchunks,
+                                                        uint2 *__restrict__ part)
 {
-    const unsigned long long x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
-    uint32_t d = __builtin_popcount((uint32_t)x0);
-    d = bcnt_acc((uint32_t)(x0 >> 32), d);
-    d = bcnt_acc((uint32_t)x1, d);
-    d = bcnt_acc((uint32_t)(x1 >> 32), d);
-    d = bcnt_acc((uint32_t)x2, d);
-    d = bcnt_acc((uint32_t)(x2 >> 32), d);
-    d = bcnt_acc((uint32_t)x3, d);
-    d = bcnt_acc((uint32_t)(x3 >> 32), d);
-    return d;
+    __shared__ __attribute__((aligned(16))) uint4 stage[2][kKnnStageTiles * kTileU4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int pair = blockIdx.z, chunk = blockIdx.y;
+    const int2 qt = pairs[pair];
+    const int nq = lcounts[qt.x], nt = lcounts[qt.y];
+    const int qb = blockIdx.x * (64 * kKnnWaves);       // first query of the workgroup
+    if (qb >= nq) return;
+    const int t0 = chunk * kKnnChunk;
+    const int tn = min(nt - t0, kKnnChunk);             // trains of this chunk
+    const int tilesPerSet = kcap / 32;
+    constexpr int kMin = (int)0x80000000;
+    int k0[kKnnQT], k1[kKnnQT];
+#pragma unroll
+    for (int u = 0; u < kKnnQT; u++) k0[u] = k1[u] = kMin;
+
+    if (tn > 0) {
+        // query fragments: kKnnQT tiles x 8 K-steps, 1 KiB coalesced loads (tiles past the set's end stay inside the buffer:
+        // kcap is a multiple of 64; their columns are never stored)
+        const int qtile0 = (qb >> 5) + wave * kKnnQT;
+        v4i Bf[kKnnQT][8];
+#pragma unroll
+        for (int u = 0; u < kKnnQT; u++) {
+            const int tq = min(qtile0 + u, tilesPerSet - 1);
+            const uint4 *src = E + ((size_t)qt.x * tilesPerSet + tq) * kTileU4 + lane;
+#pragma unroll
+            for (int s = 0; s < 8; s++) Bf[u][s] = __builtin_bit_cast(v4i, src[s * 64]);
+        }
+        // ninth K-step, query side: multipliers (1, 64) on k = 0, 1 (lane half 0, bytes 0, 1)
+        const v4i B9 = {half == 0 ? 0x4001 : 0, 0, 0, 0};
+        const uint4 *Et = E + ((size_t)qt.y * tilesPerSet + (t0 >> 5)) * kTileU4;
+        const int nstage = (tn + 32 * kKnnStageTiles - 1) / (32 * kKnnStageTiles);
+        constexpr int kPer = kKnnStageTiles * kTileU4 / (64 * kKnnWaves);   // uint4 per thread per stage (4)
+        uint4 pre[kPer];
+        auto fetch = [&](int st) {   // tiles wholly past the end are not fetched (their LDS content is never used)
+#pragma unroll
+            for (int k = 0; k < kPer; k++) {
+                const int e = k * (64 * kKnnWaves) + tid;   // element of the stage
+                pre[k] = (st * kKnnStageTiles + e / kTileU4) * 32 < tn ? Et[(size_t)st * kKnnStageTiles * kTileU4 + e] : uint4{0, 0, 0, 0};
+            }
+        };
+        auto commit = [&](int buf) {
+#pragma unroll
+            for (int k = 0; k < kPer; k++) stage[buf][k * (64 * kKnnWaves) + tid] = pre[k];
+        };
+        fetch(0);
+        commit(0);
+        __syncthreads();
+        for (int st = 0; st < nstage; st++) {
+            if (st + 1 < nstage) fetch(st + 1);   // travels while this stage is multiplied
+            const uint4 *S = stage[st & 1];
+#pragma unroll
+            for (int tl = 0; tl < kKnnStageTiles; tl++) {
+                const int tb = (st * kKnnStageTiles + tl) * 32;   // first train of the tile, relative to t0
+                if (tb >= tn) break;
+                v16i acc[kKnnQT];
+#pragma unroll
+                for (int u = 0; u < kKnnQT; u++) acc[u] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < 8; s++) {
+                    const v4i A = __builtin_bit_cast(v4i, S[(tl * 8 + s) * 64 + lane]);
+#pragma unroll
+                    for (int u = 0; u < kKnnQT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, Bf[u][s], acc[u], 0, 0, 0);
+                }
+                {   // ninth K-step, train side: 8191 - (index inside the chunk) as two digits of base 64
+                    const int iv = 8191 - (tb + (lane & 31));
+                    const v4i A9 = {half == 0 ? ((iv & 63) | ((iv >> 6) << 8)) : 0, 0, 0, 0};
+#pragma unroll
+                    for (int u = 0; u < kKnnQT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A9, B9, acc[u], 0, 0, 0);
+                }
+                if (tb + 32 > tn) {   // last tile of the set: rows past the end hold stale bytes
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const bool ok = tb + (e & 3) + 8 * (e >> 2) + 4 * half < tn;   // C/D layout: row = (e&3) + 8 (e>>2) + 4 (lane>>5)
+#pragma unroll
+                        for (int u = 0; u < kKnnQT; u++) acc[u][e] = ok ? acc[u][e] : kMin;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < kKnnQT; u++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int x = acc[u][e];
+                        k1[u] = med3_i32(k0[u], k1[u], x);   // second largest of {k0, k1, x} (k0 >= k1)
+                        k0[u] = max(k0[u], x);
+                    }
+            }
+            if (st + 1 < nstage) commit((st + 1) & 1);
+            __syncthreads();
+        }
+    }
+    // the two lane halves hold different train rows of the same query columns: merge, convert, store
+    uint2 *out = part + ((size_t)pair * nchunks + chunk) * kcap;
+#pragma unroll
+    for (int u = 0; u < kKnnQT; u++) {
+        const int o0 = __shfl_xor(k0[u], 32), o1 = __shfl_xor(k1[u], 32);
+        const int m0 = max(k0[u], o0), m1 = max(min(k0[u], o0), max(k1[u], o1));
+        const int q = qb + (wave * kKnnQT + u) * 32 + (lane & 31);
+        if (half == 0 && q < nq) {
+            auto conv = [&](int key) -> uint32_t {
+                if (key == kMin) return 0xffffffffu;
+                const uint32_t kp = (uint32_t)(key + (1 << 20));            // 8192 * (256 - hamming) + (8191 - index)
+                return ((256u - (kp >> 13)) << 16) | (uint32_t)(t0 + 8191 - (int)(kp & 8191u));
+            };
+            out[q] = uint2{conv(m0), conv(m1)};
+        }
+    }
 }
 
 __device__ __forceinline__ void knn_insert(uint32_t key, uint32_t &k0, uint32_t &k1)
@@ -975,58 +1124,6 @@ __device__ __forceinline__ void knn_insert(uint32_t key, uint32_t &k0, uint32_t 
     const uint32_t hi = key > k0 ? key : k0;   // k0 <= k1 always: v_max, v_min, v_min
     k1 = hi < k1 ? hi : k1;
     k0 = key < k0 ? key : k0;
-}
-
-// kKnnQpl queries per lane (q, q+64, ...): every broadcast LDS read of a train descriptor feeds
-// kKnnQpl distance evaluations, which divides the LDS traffic per distance and gives each wave
-// kKnnQpl independent dependency chains.
-constexpr int kKnnQpl = 1;
-constexpr int kKnnWG = 256;   // threads per workgroup
-
-__global__ __launch_bounds__(kKnnWG) void k_knn2(const uint8_t *__restrict__ desc, const int *__restrict__ counts,
-                                             const int2 *__restrict__ pairs, int kcap, int nchunks,
-                                             uint2 *__restrict__ part)
-{
-    __shared__ __attribute__((aligned(16))) ulonglong4 tr[kKnnChunk];
-    const int lane = threadIdx.x;   // kKnnWG / 64 waves share one staged train chunk
-    const int pair = blockIdx.z, chunk = blockIdx.y;
-    const int2 qt = pairs[pair];
-    const int nq = min(max(counts[qt.x], 0), kcap), nt = min(max(counts[qt.y], 0), kcap);   // (external counts: never trust a length)
-    const int q0 = blockIdx.x * (kKnnWG * kKnnQpl) + lane;
-    const int t0 = chunk * kKnnChunk;
-    if (blockIdx.x * (kKnnWG * kKnnQpl) >= nq) return;
-    uint32_t k0[kKnnQpl], k1[kKnnQpl];
-#pragma unroll
-    for (int u = 0; u < kKnnQpl; u++) k0[u] = k1[u] = 0xffffffffu;
-    if (t0 < nt) {
-        const int tn = nt - t0 < kKnnChunk ? nt - t0 : kKnnChunk;
-        // (fetching the wave-uniform train descriptor with scalar loads instead of LDS broadcasts was measured
-        // slower: 125 vs 118 us -- the s_load latency is not hidden with four in flight per wave)
-        const ulonglong4 *tsrc = reinterpret_cast<const ulonglong4 *>(desc + ((size_t)qt.y * kcap + t0) * 32);
-        for (int i = lane; i < tn; i += kKnnWG) tr[i] = tsrc[i];
-        __syncthreads();
-        ulonglong4 v[kKnnQpl];
-#pragma unroll
-        for (int u = 0; u < kKnnQpl; u++) {
-            v[u] = ulonglong4{0, 0, 0, 0};
-            if (q0 + kKnnWG * u < nq) v[u] = *reinterpret_cast<const ulonglong4 *>(desc + ((size_t)qt.x * kcap + q0 + kKnnWG * u) * 32);
-        }
-        auto step = [&](int j) {
-            const ulonglong4 t = tr[j];
-            const uint32_t tj = (uint32_t)(t0 + j);
-#pragma unroll
-            for (int u = 0; u < kKnnQpl; u++) knn_insert((hamming256(v[u], t) << 16) | tj, k0[u], k1[u]);
-        };
-        int j = 0;
-        for (; j + 4 <= tn; j += 4) {   // manual unroll: four broadcast LDS reads in flight per iteration
-            step(j); step(j + 1); step(j + 2); step(j + 3);
-        }
-        for (; j < tn; j++) step(j);
-    }
-    uint2 *out = part + ((size_t)pair * nchunks + chunk) * kcap;
-#pragma unroll
-    for (int u = 0; u < kKnnQpl; u++)
-        if (q0 + kKnnWG * u < nq) out[q0 + kKnnWG * u] = uint2{k0[u], k1[u]};
 }
 
 // Merge chunk partials, emit the knnMatch table and BruteForceMatch's accept
@@ -1084,6 +1181,28 @@ __global__ __launch_bounds__(1024) void k_knn2_finalize(const uint2 *__restrict_
         __syncthreads();
     }
     if (tid == 0) mcount[pair] = s_run;
+}
+
+// popcount(x) + acc in one instruction; chaining the eight words of a 256-bit XOR through the
+// accumulator operand saves the separate adds the compiler otherwise emits
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t hamming256(const ulonglong4 &a, const ulonglong4 &b)
+{
+    const unsigned long long x0 = a.x ^ b.x, x1 = a.y ^ b.y, x2 = a.z ^ b.z, x3 = a.w ^ b.w;
+    uint32_t d = __builtin_popcount((uint32_t)x0);
+    d = bcnt_acc((uint32_t)(x0 >> 32), d);
+    d = bcnt_acc((uint32_t)x1, d);
+    d = bcnt_acc((uint32_t)(x1 >> 32), d);
+    d = bcnt_acc((uint32_t)x2, d);
+    d = bcnt_acc((uint32_t)(x2 >> 32), d);
+    d = bcnt_acc((uint32_t)x3, d);
+    d = bcnt_acc((uint32_t)(x3 >> 32), d);
+    return d;
 }
 
 // ---------------------------------------------------------------------------
@@ -1239,14 +1358,21 @@ void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, co
     }
 }
 
-void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const int2 *pairs, int npairs, int kcap,
-                 uint2 *part, float dist_thresh, float ratio, KnnRow *out, uint32_t *mlist, int *mcount, hipEvent_t ev_mid)
+void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const int *setmap, int nsets, const int2 *pairs, int npairs,
+                 int kcap, void *expanded, int *lcounts, uint2 *part, float dist_thresh, float ratio, KnnRow *out, uint32_t *mlist,
+                 int *mcount, hipEvent_t ev_exp, hipEvent_t ev_mid)
 {
+    uint4 *E = reinterpret_cast<uint4 *>(expanded);
+    hipLaunchKernelGGL(k_expand, dim3((kcap + 255) / 256, nsets), dim3(256), 0, st, desc, counts, setmap, kcap, E, lcounts);
+    if (ev_exp) (void)hipEventRecord(ev_exp, st);
     const int nchunks = (kcap + kKnnChunk - 1) / kKnnChunk;
-    dim3 grid((kcap + kKnnWG * kKnnQpl - 1) / (kKnnWG * kKnnQpl), nchunks, npairs);
-    hipLaunchKernelGGL(k_knn2, grid, dim3(kKnnWG), 0, st, desc, counts, pairs, kcap, nchunks, part);
+    dim3 grid((kcap + 64 * kKnnWaves - 1) / (64 * kKnnWaves), nchunks, npairs);
+    static const int stage_env = getenv("MCORB_KNN_STAGE") ? atoi(getenv("MCORB_KNN_STAGE")) : 0;
+    if (stage_env == 1) hipLaunchKernelGGL(k_knn2<1>, grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, part);
+    else if (stage_env == 4) hipLaunchKernelGGL(k_knn2<4>, grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, part);
+    else hipLaunchKernelGGL(k_knn2<2>, grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, part);
     if (ev_mid) (void)hipEventRecord(ev_mid, st);
-    hipLaunchKernelGGL(k_knn2_finalize, dim3(npairs), dim3(1024), 0, st, part, counts, pairs, kcap, nchunks, dist_thresh, ratio, out, mlist,
+    hipLaunchKernelGGL(k_knn2_finalize, dim3(npairs), dim3(1024), 0, st, part, lcounts, pairs, kcap, nchunks, dist_thresh, ratio, out, mlist,
                        mcount);
 }
 

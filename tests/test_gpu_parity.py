@@ -320,6 +320,12 @@ def test_match_ratio_and_dist_ratio_helpers(mc):
     mA, mB, book = ext.getMatches_distRatio(A, iA, B, iB)
     oA, oB, obook = O.get_matches_dist_ratio(A, iA, B, iB)
     assert np.array_equal(mA, oA) and np.array_equal(mB, oB) and book == obook
+    # duplicate descriptors: best and second-best distance both 0 -> 0/0 = NaN in the reference, the feature is skipped
+    B2 = np.concatenate([A[:5], A[:5], B[5:60]])
+    mA, mB, book = ext.getMatches_distRatio(A, np.arange(40), B2, np.arange(len(B2)))
+    oA, oB, obook = O.get_matches_dist_ratio(A, np.arange(40), B2, np.arange(len(B2)))
+    assert np.array_equal(mA, oA) and np.array_equal(mB, oB) and book == obook
+    assert not set(range(5)) & set(mA.tolist())
 
 
 # --------------------------------------------------------------------------------------------

@@ -18,7 +18,7 @@ def main():
     dump = "--dump" in sys.argv
     os.makedirs(OUT, exist_ok=True)
     src = os.path.join(ROOT, "mc-slam_amd", "csrc", "mcorb_kernels.hip")
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950",
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--offload-arch=gfx950", "-mllvm", "-amdgpu-mfma-vgpr-form",
                            "-I" + os.path.join(ROOT, "mc-slam_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
                            "--save-temps", "-c", src, "-o", os.path.join(OUT, "k.o")], cwd=OUT)
     asm = open(os.path.join(OUT, "mcorb_kernels-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
