@@ -274,9 +274,24 @@ int mcorb_rig_transform_image(mcorb_rig *r, int slot, int m, mcorb_vocab *v, int
  * best / second-best distance table on the GPU, the reference's serial track bookkeeping on the host.
  * tracks: ntracks x ncams matchIndex rows (-1 absent); n_rays per track; words: node id pushed to
  * words_ for every accepted feature.  max_neighbor_ratio = ORBextractor::max_neighbor_ratio (0.85). */
+/* transform() of images [img0, img0 + nimg) of a slot at once (one descent launch; the order-defined folds of the
+ * images run on the worker pool); read each image's vectors with mcorb_rig_get_transform (layout as
+ * mcorb_vocab_transform's outputs) */
+int mcorb_rig_transform_images(mcorb_rig *r, int slot, int img0, int nimg, mcorb_vocab *v, int levelsup);
+int mcorb_rig_get_transform(mcorb_rig *r, int slot, int m, uint32_t *bow_ids, double *bow_vals, int bow_cap, int *nbow,
+                            uint32_t *fv_nodes, int32_t *fv_offsets, int fv_cap, int *nfv, int32_t *fv_feats, int feat_cap);
 int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_vocab *v, int levelsup, double max_neighbor_ratio,
                         int32_t *tracks, int32_t *n_rays, int cap_tracks, int *ntracks_out, uint32_t *words,
                         int cap_words, int *nwords_out);
+/* The same for frames [frame0, frame0 + nframes) of a slot at once (one descent launch, one table launch, the serial
+ * bookkeeping of the frames on the worker pool); results are kept per frame and read with mcorb_rig_get_bow_tracks.
+ * y_undist (may be NULL): y_undist[m], m = frame * ncams + cam, points at the undistorted rows of image m's keypoints --
+ * image_kps_undist[cam][k].pt.y, which the reference's |dy| < 50 gate reads (MultiCameraFrame.cpp:708-716); NULL = the raw
+ * rows (RECTIFY, or zero distortion: image_kps_undist == image_kps, MultiCameraFrame.cpp:302-307). */
+int mcorb_rig_match_bow_frames(mcorb_rig *r, int slot, int frame0, int nframes, mcorb_vocab *v, int levelsup,
+                               double max_neighbor_ratio, const float *const *y_undist);
+int mcorb_rig_get_bow_tracks(mcorb_rig *r, int slot, int frame, int32_t *tracks, int32_t *n_rays, int cap_tracks,
+                             int *ntracks_out, uint32_t *words, int cap_words, int *nwords_out);
 
 /* ------------------------------------------------------------------------- */
 /* Host stages exposed for the CPU test-suite (no device needed)              */

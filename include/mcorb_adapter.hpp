@@ -265,6 +265,7 @@ public:
             image_kps[c].resize(n);
             image_descriptors[c].resize((size_t)n * 32);
         }
+        image_kps_undist.clear();   // belongs to the previous frame
         matched_ = false;
     }
     // BruteForceMatch (MultiCameraFrame.cpp:1024-1086), cam1 < cam2 as at every reference call site
@@ -280,9 +281,13 @@ public:
               "mcorb_rig_get_pair_matches");
         indices_1.resize(n); indices_2.resize(n);
         kps1.clear(); kps2.clear();
+        // the reference returns image_kps_undist (:1069-1076): the caller's undistorted set when one was given
+        // (setUndistorted), else the extracted keypoints (RECTIFY, or zero distortion: UndistortKeyPoints copies them, :302-305)
+        const std::vector<mcorb_keypoint> &u1 = undist_ok(img1_ind) ? image_kps_undist[img1_ind] : image_kps[img1_ind];
+        const std::vector<mcorb_keypoint> &u2 = undist_ok(img2_ind) ? image_kps_undist[img2_ind] : image_kps[img2_ind];
         for (int k = 0; k < n; k++) {
-            kps1.push_back(image_kps[img1_ind][indices_1[k]]);   // image_kps_undist == image_kps (RECTIFY=false)
-            kps2.push_back(image_kps[img2_ind][indices_2[k]]);
+            kps1.push_back(u1[indices_1[k]]);
+            kps2.push_back(u2[indices_2[k]]);
         }
     }
     // The per-pair fundamental matrices the old=true branch builds from camconfig_ (MultiCameraFrame.cpp:1126-1142),
@@ -323,8 +328,21 @@ public:
         std::vector<int32_t> tr((size_t)cap * num_cams_), rays(cap);
         std::vector<uint32_t> w(cap);
         int n = 0, nw = 0;
-        check(mcorb_rig_match_bow(rig_, 0, 0, voc.handle(), levelsup, max_neighbor_ratio, tr.data(), rays.data(), cap, &n, w.data(), cap, &nw),
-              "mcorb_rig_match_bow");
+        // the |dy| < 50 gate reads image_kps_undist[cam][k].pt.y (:708-716)
+        std::vector<std::vector<float>> yu(num_cams_);
+        std::vector<const float *> yp(num_cams_, nullptr);
+        for (int c = 0; c < num_cams_; c++)
+            if (undist_ok(c)) {
+                for (const mcorb_keypoint &k : image_kps_undist[c]) yu[c].push_back(k.y);
+                yp[c] = yu[c].data();
+            }
+        bool any = false;
+        for (int c = 0; c < num_cams_; c++) any = any || yp[c];
+        if (any)
+            for (int c = 0; c < num_cams_; c++)
+                if (!yp[c]) { for (const mcorb_keypoint &k : image_kps[c]) yu[c].push_back(k.y); yp[c] = yu[c].data(); }
+        check(mcorb_rig_match_bow_frames(rig_, 0, 0, 1, voc.handle(), levelsup, max_neighbor_ratio, any ? yp.data() : nullptr), "mcorb_rig_match_bow_frames");
+        check(mcorb_rig_get_bow_tracks(rig_, 0, 0, tr.data(), rays.data(), cap, &n, w.data(), cap, &nw), "mcorb_rig_get_bow_tracks");
         matches.clear();
         matches.resize(n);
         for (int m = 0; m < n; m++) {
@@ -347,8 +365,12 @@ public:
         ORBVocabulary::fill(ids, vals, nb, nodes, offs, feats, nf, bow, fv);
     }
 
-    // image_kps_undist for the epipolar check; by default the extracted keypoints are used (RECTIFY=false)
+    // image_kps_undist (MultiCameraFrame.cpp:241-245): what UndistortKeyPoints (:300-347) produced for the current frame.  Read by
+    // BruteForceMatch's returned keypoints, the epipolar check and the BoW-guided matcher's row gate.  Not needed when RECTIFY is
+    // on or the distortion is zero: the reference then copies image_kps, which is the default here.  Call after
+    // extractFeaturesParallel(); it is dropped by the next extraction.
     void setUndistorted(const std::vector<std::vector<mcorb_keypoint>> &kps_undist) { image_kps_undist = kps_undist; }
+    bool undist_ok(int c) const { return (int)image_kps_undist.size() == num_cams_ && image_kps_undist[c].size() == image_kps[c].size() && !image_kps[c].empty(); }
 
     // computeIntraMatches(matches, old) (MultiCameraFrame.cpp:1100-1288)
     void computeIntraMatches(std::vector<IntraMatch> &matches, bool old)

@@ -454,6 +454,40 @@ class ORBVocabulary:
                                                nr.ctypes.data, cap, C.byref(nt), words.ctypes.data, cap, C.byref(nw)))
         return tr[:nt.value].copy(), nr[:nt.value].copy(), words[:nw.value].copy()
 
+    def match_rig_frames(self, rig, frame0, nframes, slot=0, levelsup=4, max_neighbor_ratio=0.85, y_undist=None):
+        """computeIntraMatches(matches, words_) for frames [frame0, frame0 + nframes) at once -> list of (tracks, n_rays, words).
+        y_undist: optional list, one float32 array per image of the SLOT (index frame * ncams + cam; None entries allowed for
+        images outside the range) = image_kps_undist[cam][k].pt.y, the rows the reference's |dy| < 50 gate reads."""
+        ptrs, keep = None, []
+        if y_undist is not None:
+            arr = (C.c_void_p * len(y_undist))()
+            for i, y in enumerate(y_undist):
+                if y is not None:
+                    a = np.ascontiguousarray(y, np.float32)
+                    keep.append(a)
+                    arr[i] = a.ctypes.data
+            ptrs = arr
+        _lib.check(self.L_.mcorb_rig_match_bow_frames(rig.h_rig, slot, frame0, nframes, self.h, levelsup, max_neighbor_ratio, ptrs))
+        out, cap = [], rig.kcap * rig.ncams
+        for f in range(frame0, frame0 + nframes):
+            tr = np.full((cap, rig.ncams), -1, np.int32)
+            nr = np.zeros(cap, np.int32)
+            words = np.zeros(cap, np.uint32)
+            nt, nw = C.c_int(), C.c_int()
+            _lib.check(self.L_.mcorb_rig_get_bow_tracks(rig.h_rig, slot, f, tr.ctypes.data, nr.ctypes.data, cap, C.byref(nt),
+                                                        words.ctypes.data, cap, C.byref(nw)))
+            out.append((tr[:nt.value].copy(), nr[:nt.value].copy(), words[:nw.value].copy()))
+        return out
+
+    def transform_rig_images(self, rig, img0, nimg, slot=0, levelsup=4):
+        """transform() of images [img0, img0 + nimg) of a slot in one call -> list of (BowVector, FeatureVector)."""
+        _lib.check(self.L_.mcorb_rig_transform_images(rig.h_rig, slot, img0, nimg, self.h, levelsup))
+        out = []
+        for m in range(img0, img0 + nimg):
+            n = max(rig.L.mcorb_rig_num_keypoints(rig.h_rig, slot, m), 0)
+            out.append(self._call(lambda *a, m=m: self.L_.mcorb_rig_get_transform(rig.h_rig, slot, m, *a[1:]), (), n, levelsup))   # (a[0] = levelsup)
+        return out
+
     def transform_rig_image(self, rig, m, slot=0, levelsup=4):
         """transform() of image m's descriptors straight from the rig's HBM buffers (MultiCameraFrame.cpp:257)."""
         n = rig.L.mcorb_rig_num_keypoints(rig.h_rig, slot, m)
@@ -511,10 +545,18 @@ class MultiCameraFrame:
             _, k, d = self.rig.features(c)
             self.image_kps.append(k)
             self.image_descriptors.append(d)
-        self.image_kps_undist = self.image_kps   # RECTIFY=false, zero distortion branch (:302-305)
+        self.image_kps_undist = self.image_kps   # RECTIFY, or zero distortion: UndistortKeyPoints copies (:241-242, :302-305)
         self._matched = False
 
     extractFeatures = extractFeaturesParallel
+
+    def setUndistorted(self, image_kps_undist):
+        """image_kps_undist as UndistortKeyPoints (MultiCameraFrame.cpp:300-347) fills it for a distorted, unrectified rig
+        (cv::undistortPoints is the caller's).  Read by BruteForceMatch's returned keypoints, the epipolar check of
+        computeIntraMatches(old=True) and the BoW-guided matcher's |dy| < 50 gate.  Call after extractFeaturesParallel()."""
+        if len(image_kps_undist) != self.num_cams_ or any(len(u) != len(k) for u, k in zip(image_kps_undist, self.image_kps)):
+            raise ValueError("image_kps_undist must hold one entry per extracted keypoint")
+        self.image_kps_undist = list(image_kps_undist)
 
     def _ensure_match(self, dist_thresh, ratio):
         key = (float(dist_thresh), float(ratio))
@@ -531,8 +573,10 @@ class MultiCameraFrame:
         return i1, i2, self.image_kps_undist[img1_ind][i1], self.image_kps_undist[img2_ind][i2]
 
     def computeIntraMatchesBoW(self, vocabulary, words_=None, levelsup=4):
-        """computeIntraMatches(matches, words_) (MultiCameraFrame.cpp:586-943), the call FrontEnd.cpp:1009 makes."""
-        tr, nr, words = vocabulary.match_rig_frame(self.rig, 0, levelsup=levelsup)
+        """computeIntraMatches(matches, words_) (MultiCameraFrame.cpp:586-943), the call FrontEnd.cpp:1009 makes.  The
+        |dy| < 50 gate reads image_kps_undist (:708-716): set it with setUndistorted() when the rig is not rectified."""
+        yu = [np.ascontiguousarray(k["y"], np.float32) for k in self.image_kps_undist]
+        tr, nr, words = vocabulary.match_rig_frames(self.rig, 0, 1, levelsup=levelsup, y_undist=yu)[0]
         if words_ is not None:
             words_.extend(int(w) for w in words)
         out = [IntraMatch(row) for row in tr]
@@ -553,7 +597,8 @@ class MultiCameraFrame:
         if old:
             if getattr(self, "F_mats", None) is None:
                 raise ValueError("computeIntraMatches(old=True) needs setCalibration(K, R, t) or F_mats")
-            tr, mergeable = self.rig.tracks_epipolar(0, self.F_mats, kps_undist)
+            tr, mergeable = self.rig.tracks_epipolar(0, self.F_mats, kps_undist if kps_undist is not None else
+                                                     (self.image_kps_undist if self.image_kps_undist is not self.image_kps else None))
         else:
             tr, mergeable = self.rig.tracks(0)
         self.cnt_mergable_matches = mergeable

@@ -94,6 +94,10 @@ SIGNATURES = {
     "mcorb_rig_transform_image": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _i, _ip, _vp, _vp, _i, _ip, _vp, _i]),
     "mcorb_rig_get_tracks_epipolar": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _ip, _ip]),
     "mcorb_rig_match_bow": (_i, [_vp, _i, _i, _vp, _i, C.c_double, _vp, _vp, _i, _ip, _vp, _i, _ip]),
+    "mcorb_rig_transform_images": (_i, [_vp, _i, _i, _i, _vp, _i]),
+    "mcorb_rig_get_transform": (_i, [_vp, _i, _i, _vp, _vp, _i, _ip, _vp, _vp, _i, _ip, _vp, _i]),
+    "mcorb_rig_match_bow_frames": (_i, [_vp, _i, _i, _i, _vp, _i, C.c_double, _vp]),
+    "mcorb_rig_get_bow_tracks": (_i, [_vp, _i, _i, _vp, _vp, _i, _ip, _vp, _i, _ip]),
     "mcorb_host_select": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i]),
     "mcorb_host_resize_axis": (_i, [_i, _i, _i, _vp]),
     "mcorb_host_geometry": (_i, [C.POINTER(Params), _i, _i, _vp]),

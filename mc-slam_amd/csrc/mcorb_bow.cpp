@@ -328,93 +328,177 @@ extern "C" int mcorb_rig_transform_image(mcorb_rig *r, int slot, int m, mcorb_vo
                             fv_nodes, fv_offsets, fv_cap, nfv, fv_feats, feat_cap);
 }
 
-// ---------------------------------------------------------------------------
-// computeIntraMatches(matches, words_): the BoW-guided live variant (MultiCameraFrame.cpp:586-943).
-// GPU: vocabulary descent of every camera's descriptors + the per-node best/second-best table
-// (k_bow_best2).  Host: the reference's serial iteration over common nodes and its track
-// bookkeeping (new track / extend / merge into an existing one / override), replayed on that table.
-// ---------------------------------------------------------------------------
-namespace {
-struct BowTrack { int matchIndex[MCORB_MAX_CAMS]; int n_rays; };
-}
-
-extern "C" int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_vocab *v, int levelsup, double max_neighbor_ratio,
-                                   int32_t *tracks, int32_t *n_rays, int cap_tracks, int *ntracks_out, uint32_t *words,
-                                   int cap_words, int *nwords_out)
+// transform() of images [img0, img0 + nimg) of a slot in one go (what extractFeaturesParallel's per-camera threads do,
+// MultiCameraFrame.cpp:257): one descent launch, one read-back, the order-defined folds of the images on the worker pool.
+extern "C" int mcorb_rig_transform_images(mcorb_rig *r, int slot, int img0, int nimg, mcorb_vocab *v, int levelsup)
 {
-    if (ntracks_out) *ntracks_out = 0;
-    if (nwords_out) *nwords_out = 0;
-    if (!r || !v || slot < 0 || slot >= (int)r->rig.slots.size() || !tracks) { set_error("match_bow: bad argument"); return MCORB_E_ARG; }
+    if (!r || !v || slot < 0 || slot >= (int)r->rig.slots.size() || nimg < 1) { set_error("rig transform: bad argument"); return MCORB_E_ARG; }
     Rig &R = r->rig;
     Slot *s = R.slots[slot];
     {
         std::lock_guard<std::mutex> lk(s->m);
         if (s->busy) { set_error("slot busy"); return MCORB_E_STATE; }
     }
-    const int C = R.ncams, kcap = R.geom.kcap;
-    if (frame < 0 || (frame + 1) * C > s->nimg_done) { set_error("match_bow: frame not extracted"); return MCORB_E_STATE; }
+    if (img0 < 0 || img0 + nimg > s->nimg_done) { set_error("image index out of range"); return MCORB_E_ARG; }
+    if (v->device != R.device) { set_error("vocabulary lives on another device"); return MCORB_E_ARG; }
+    HIPCHK(hipSetDevice(v->device));
+    const int kcap = R.geom.kcap;
+    int st = ensure_scratch(v, nimg * kcap);
+    if (st != MCORB_OK) return st;
+    launch_bow_descend(s->st, s->d_desc + (size_t)img0 * kcap * 32, nimg * kcap, v->d_child_start, v->d_child_count, v->d_child_desc,
+                       v->d_child_id, v->d_word_id, v->d_weight, v->L - levelsup, v->d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(v->h_out, v->d_out, (size_t)nimg * kcap * sizeof(mcorb::BowRes), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    if ((int)s->bowvec.size() < R.max_images) { s->bowvec.resize(R.max_images); s->bowvec_ok.assign(R.max_images, 0); }
+    R.pool->parallel_for(nimg, [&](int i, int) {
+        BowList bow;
+        std::map<uint32_t, std::vector<int32_t>> fv;
+        assemble(v, v->h_out + (size_t)i * kcap, s->h_nsel[img0 + i], bow, fv);
+        BowImageOut &o = s->bowvec[img0 + i];
+        o.bow_ids.clear(); o.bow_vals.clear(); o.fv_nodes.clear(); o.fv_offsets.clear(); o.fv_feats.clear();
+        for (auto &e : bow) { o.bow_ids.push_back(e.first); o.bow_vals.push_back(e.second); }
+        for (auto &e : fv) {
+            o.fv_nodes.push_back(e.first);
+            o.fv_offsets.push_back((int32_t)o.fv_feats.size());
+            o.fv_feats.insert(o.fv_feats.end(), e.second.begin(), e.second.end());
+        }
+        o.fv_offsets.push_back((int32_t)o.fv_feats.size());
+        s->bowvec_ok[img0 + i] = 1;
+    }, R.pool_threads + s->index);
+    return MCORB_OK;
+}
+
+extern "C" int mcorb_rig_get_transform(mcorb_rig *r, int slot, int m, uint32_t *bow_ids, double *bow_vals, int bow_cap, int *nbow,
+                                       uint32_t *fv_nodes, int32_t *fv_offsets, int fv_cap, int *nfv, int32_t *fv_feats, int feat_cap)
+{
+    if (!r || slot < 0 || slot >= (int)r->rig.slots.size()) { set_error("get transform: bad argument"); return MCORB_E_ARG; }
+    Slot *s = r->rig.slots[slot];
+    if (m < 0 || m >= (int)s->bowvec.size() || !s->bowvec_ok[m]) { set_error("get transform: image not transformed"); return MCORB_E_STATE; }
+    const BowImageOut &o = s->bowvec[m];
+    if (nbow) *nbow = (int)o.bow_ids.size();
+    if (nfv) *nfv = (int)o.fv_nodes.size();
+    if ((int)o.bow_ids.size() > bow_cap || (int)o.fv_nodes.size() > fv_cap || (int)o.fv_feats.size() > feat_cap) { set_error("transform: output too small"); return MCORB_E_CAP; }
+    if (!o.bow_ids.empty()) { memcpy(bow_ids, o.bow_ids.data(), o.bow_ids.size() * 4); memcpy(bow_vals, o.bow_vals.data(), o.bow_vals.size() * 8); }
+    if (!o.fv_nodes.empty()) memcpy(fv_nodes, o.fv_nodes.data(), o.fv_nodes.size() * 4);
+    memcpy(fv_offsets, o.fv_offsets.data(), o.fv_offsets.size() * 4);
+    if (!o.fv_feats.empty()) memcpy(fv_feats, o.fv_feats.data(), o.fv_feats.size() * 4);
+    return MCORB_OK;
+}
+
+// ---------------------------------------------------------------------------
+// computeIntraMatches(matches, words_): the BoW-guided live variant (MultiCameraFrame.cpp:586-943).
+// GPU: vocabulary descent of every camera's descriptors + the per-node best/second-best table
+// (k_bow_best2), both for ALL frames of the batch in one launch each.  Host: the reference's serial
+// iteration over common nodes and its track bookkeeping (new track / extend / merge into an existing one /
+// override), replayed on that table, one worker-pool task per frame.
+// A FeatureVector is DBoW2's std::map<node id, vector<feature index>>; here it is the equivalent sorted list of
+// (node id, run of feature indices in feature order) -- iteration order and contents are the map's.
+// ---------------------------------------------------------------------------
+namespace {
+struct BowTrack { int matchIndex[MCORB_MAX_CAMS]; int n_rays; };
+struct FvRun { uint32_t node; int beg, cnt; };          // features fv_feats[beg .. beg + cnt)
+struct FrameTables {                                    // per frame, built on the host between the two GPU phases
+    std::vector<std::vector<FvRun>> fv;                 // per camera
+    std::vector<std::vector<int32_t>> feats;            // per camera: feature indices, node-major
+    std::vector<uint32_t> slots;                        // distinct node ids over all cameras, ascending
+    bool empty = false;                                 // some camera has no feature vector: the reference returns no matches
+};
+}  // namespace
+
+static int pair_of(int C, int c1, int c2) { return c1 * C - c1 * (c1 + 1) / 2 + (c2 - c1 - 1); }
+
+extern "C" int mcorb_rig_match_bow_frames(mcorb_rig *r, int slot, int frame0, int nframes, mcorb_vocab *v, int levelsup,
+                                          double max_neighbor_ratio, const float *const *y_undist)
+{
+    if (!r || !v || slot < 0 || slot >= (int)r->rig.slots.size() || nframes < 1) { set_error("match_bow: bad argument"); return MCORB_E_ARG; }
+    Rig &R = r->rig;
+    Slot *s = R.slots[slot];
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        if (s->busy) { set_error("slot busy"); return MCORB_E_STATE; }
+    }
+    const int C = R.ncams, kcap = R.geom.kcap, npairs = C * (C - 1) / 2;
+    if (frame0 < 0 || (frame0 + nframes) * C > s->nimg_done) { set_error("match_bow: frames not extracted"); return MCORB_E_STATE; }
     if (v->device != R.device) { set_error("vocabulary lives on another device"); return MCORB_E_ARG; }
     HIPCHK(hipSetDevice(R.device));
     const int TH_LOW = 75;   // ORBextractor.h:27
+    const int img0 = frame0 * C, nimg = nframes * C;
+    if ((int)s->bow.size() < R.max_frames) s->bow.resize(R.max_frames);
 
     static const bool prof = getenv("MCORB_HOST_PROF") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
     const auto T0 = now();
-    auto T1 = T0, T2 = T0, T3 = T0, T4 = T0;
-    // 1. FeatureVector of every camera (transform(..., levelsup), MultiCameraFrame.cpp:257): all descents are
-    //    queued back to back, one read-back, one synchronisation
-    std::vector<std::map<uint32_t, std::vector<int32_t>>> fvs(C);
-    std::vector<int> nfeat(C);
-    {
-        int st = ensure_scratch(v, C * kcap);
-        if (st != MCORB_OK) return st;
-        for (int c = 0; c < C; c++) {
-            const int m = frame * C + c, n = s->h_nsel[m];
-            nfeat[c] = n;
-            if (n > 0)
-                launch_bow_descend(s->st, s->d_desc + (size_t)m * kcap * 32, n, v->d_child_start, v->d_child_count, v->d_child_desc,
-                                   v->d_child_id, v->d_word_id, v->d_weight, v->L - levelsup, v->d_out + (size_t)c * kcap);
-        }
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(v->h_out, v->d_out, (size_t)C * kcap * sizeof(mcorb::BowRes), hipMemcpyDeviceToHost, s->st));
-        HIPCHK(hipStreamSynchronize(s->st));
-        T1 = now();
-        for (int c = 0; c < C; c++) {
-            // FeatureVector only (addFeature for every non-stopped word, in feature order); the BowVector half of
-            // transform() is not needed here and its 2000 map insertions would dominate the call
-            const mcorb::BowRes *res = v->h_out + (size_t)c * kcap;
-            for (int i = 0; i < nfeat[c]; i++)
-                if (res[i].weight > 0) fvs[c][(uint32_t)res[i].nodeup].push_back(i);
-            if (fvs[c].empty()) return MCORB_OK;   // the reference returns with no matches (:602-603)
-        }
-    }
 
-    T2 = now();
-    // 2. node slots (distinct node ids over all cameras) and per-(slot, camera) feature ranges
-    std::map<uint32_t, int> slot_id;
-    for (int c = 0; c < C; c++)
-        for (auto &e : fvs[c]) slot_id.emplace(e.first, 0);
-    int ns = 0;
-    for (auto &e : slot_id) e.second = ns++;
-    std::vector<int> slot_of((size_t)C * kcap, -1), node_feats((size_t)C * kcap, 0), sets(C);
-    std::vector<int2> node_range((size_t)ns * C, int2{0, 0});
-    std::vector<float> yv((size_t)C * kcap, 0.f);
-    for (int c = 0; c < C; c++) {
-        sets[c] = frame * C + c;
-        int pos = 0;
-        for (auto &e : fvs[c]) {
-            const int sl = slot_id[e.first];
-            node_range[(size_t)sl * C + c] = int2{pos, (int)e.second.size()};
-            for (int32_t f : e.second) { node_feats[(size_t)c * kcap + pos++] = f; slot_of[(size_t)c * kcap + f] = sl; }
-        }
-        const std::vector<mcorb_keypoint> &K = s->kps[frame * C + c];
-        for (size_t k = 0; k < K.size(); k++) yv[(size_t)c * kcap + k] = K[k].y;   // image_kps_undist[c][k].pt.y
-    }
+    // 1. vocabulary descent of every descriptor of the batch (transform(..., levelsup), MultiCameraFrame.cpp:257): one
+    //    launch over the slot's kcap-strided descriptor block (rows past an image's count are descended too and ignored)
+    int st = ensure_scratch(v, nimg * kcap);
+    if (st != MCORB_OK) return st;
+    launch_bow_descend(s->st, s->d_desc + (size_t)img0 * kcap * 32, nimg * kcap, v->d_child_start, v->d_child_count, v->d_child_desc,
+                       v->d_child_id, v->d_word_id, v->d_weight, v->L - levelsup, v->d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(v->h_out, v->d_out, (size_t)nimg * kcap * sizeof(mcorb::BowRes), hipMemcpyDeviceToHost, s->st));
+    HIPCHK(hipStreamSynchronize(s->st));
+    const auto T1 = now();
 
-    T3 = now();
-    // 3. best / second-best table on the GPU (scratch lives in the vocabulary object, grow-only)
-    const size_t n_i = (size_t)C * kcap * 2 + C * 2, tab_n = (size_t)C * kcap * C;
+    // 2. per frame: FeatureVectors (addFeature for every non-stopped word, in feature order; the BowVector half of
+    //    transform() is not needed here), node slots and the index tables of k_bow_best2
+    std::vector<FrameTables> ft(nframes);
+    std::vector<int> h_slot_of((size_t)nimg * kcap, -1), h_node_feats((size_t)nimg * kcap, 0), h_nfeat(nimg, 0);
+    std::vector<float> h_yv((size_t)nimg * kcap, 0.f);
+    R.pool->parallel_for(nframes, [&](int f, int) {
+        FrameTables &F = ft[f];
+        F.fv.resize(C); F.feats.resize(C);
+        std::vector<std::pair<uint32_t, int32_t>> tmp;
+        for (int c = 0; c < C; c++) {
+            const int m = f * C + c, n = s->h_nsel[img0 + m];
+            h_nfeat[m] = n;
+            const mcorb::BowRes *res = v->h_out + (size_t)m * kcap;
+            tmp.clear();
+            for (int i = 0; i < n; i++)
+                if (res[i].weight > 0) tmp.emplace_back((uint32_t)res[i].nodeup, i);
+            std::stable_sort(tmp.begin(), tmp.end(), [](const std::pair<uint32_t, int32_t> &a, const std::pair<uint32_t, int32_t> &b) { return a.first < b.first; });
+            F.feats[c].resize(tmp.size());
+            for (size_t i = 0; i < tmp.size(); i++) {
+                F.feats[c][i] = tmp[i].second;
+                if (i == 0 || tmp[i].first != tmp[i - 1].first) F.fv[c].push_back(FvRun{tmp[i].first, (int)i, 0});
+                F.fv[c].back().cnt++;
+            }
+            if (F.fv[c].empty()) F.empty = true;   // the reference returns with no matches (:602-603)
+            // image_kps_undist[c][k].pt.y (:708-716): the caller's undistorted rows, or the raw ones (RECTIFY / zero distortion)
+            const std::vector<mcorb_keypoint> &K = s->kps[img0 + m];
+            const float *yu = y_undist ? y_undist[img0 + m] : nullptr;
+            for (int k = 0; k < n; k++) h_yv[(size_t)m * kcap + k] = yu ? yu[k] : K[k].y;
+        }
+        for (int c = 0; c < C; c++)
+            for (const FvRun &e : F.fv[c]) F.slots.push_back(e.node);
+        std::sort(F.slots.begin(), F.slots.end());
+        F.slots.erase(std::unique(F.slots.begin(), F.slots.end()), F.slots.end());
+        for (int c = 0; c < C; c++) {
+            const int m = f * C + c;
+            for (const FvRun &e : F.fv[c]) {
+                const int sl = (int)(std::lower_bound(F.slots.begin(), F.slots.end(), e.node) - F.slots.begin());
+                for (int k = 0; k < e.cnt; k++) {
+                    h_node_feats[(size_t)m * kcap + e.beg + k] = F.feats[c][e.beg + k];
+                    h_slot_of[(size_t)m * kcap + F.feats[c][e.beg + k]] = sl;
+                }
+            }
+        }
+    }, R.pool_threads + s->index);
+    std::vector<int> h_rgbase(nframes + 1, 0);
+    for (int f = 0; f < nframes; f++) h_rgbase[f + 1] = h_rgbase[f] + (int)ft[f].slots.size();
+    std::vector<int2> h_rg((size_t)std::max(h_rgbase[nframes], 1) * C, int2{0, 0});
+    for (int f = 0; f < nframes; f++)
+        for (int c = 0; c < C; c++)
+            for (const FvRun &e : ft[f].fv[c]) {
+                const int sl = (int)(std::lower_bound(ft[f].slots.begin(), ft[f].slots.end(), e.node) - ft[f].slots.begin());
+                h_rg[(size_t)(h_rgbase[f] + sl) * C + c] = int2{e.beg, e.cnt};
+            }
+    const auto T2 = now();
+
+    // 3. best / second-best tables on the GPU (scratch lives in the vocabulary object, grow-only)
+    const size_t n_i = (size_t)nimg * kcap * 2 + nimg + nframes + 1, tab_n = (size_t)nframes * npairs * kcap;
     auto grow = [](void **p, size_t &cap, size_t need, size_t elem) -> bool {
         if (need <= cap) return true;
         (void)hipFree(*p);
@@ -423,148 +507,185 @@ extern "C" int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_voca
         cap = need;
         return true;
     };
-    if (!grow((void **)&v->d_mi, v->mi_cap, n_i, sizeof(int)) || !grow((void **)&v->d_my, v->my_cap, yv.size(), sizeof(float)) ||
-        !grow((void **)&v->d_mrg, v->mrg_cap, std::max<size_t>(node_range.size(), 1), sizeof(int2))) {
+    if (!grow((void **)&v->d_mi, v->mi_cap, n_i, sizeof(int)) || !grow((void **)&v->d_my, v->my_cap, h_yv.size(), sizeof(float)) ||
+        !grow((void **)&v->d_mrg, v->mrg_cap, h_rg.size(), sizeof(int2))) {
         set_error("match_bow: device allocation failed");
         return MCORB_E_HIP;
     }
-    if (tab_n > v->mtab_cap) {
+    if (std::max<size_t>(tab_n, 1) > v->mtab_cap) {
         (void)hipFree(v->d_mtab);
         if (v->h_mtab) (void)hipHostFree(v->h_mtab);
         v->d_mtab = nullptr; v->h_mtab = nullptr; v->mtab_cap = 0;
-        HIPCHK(hipMalloc((void **)&v->d_mtab, tab_n * sizeof(int4)));
-        HIPCHK(hipHostMalloc((void **)&v->h_mtab, tab_n * sizeof(int4), hipHostMallocDefault));
-        v->mtab_cap = tab_n;
+        HIPCHK(hipMalloc((void **)&v->d_mtab, std::max<size_t>(tab_n, 1) * sizeof(int4)));
+        HIPCHK(hipHostMalloc((void **)&v->h_mtab, std::max<size_t>(tab_n, 1) * sizeof(int4), hipHostMallocDefault));
+        v->mtab_cap = std::max<size_t>(tab_n, 1);
     }
-    int *d_slot_of = v->d_mi, *d_node_feats = v->d_mi + (size_t)C * kcap, *d_sets = v->d_mi + (size_t)C * kcap * 2, *d_nfeat = d_sets + C;
-    HIPCHK(hipMemcpyAsync(d_slot_of, slot_of.data(), slot_of.size() * sizeof(int), hipMemcpyHostToDevice, s->st));
-    HIPCHK(hipMemcpyAsync(d_node_feats, node_feats.data(), node_feats.size() * sizeof(int), hipMemcpyHostToDevice, s->st));
-    HIPCHK(hipMemcpyAsync(d_sets, sets.data(), C * sizeof(int), hipMemcpyHostToDevice, s->st));
-    HIPCHK(hipMemcpyAsync(d_nfeat, nfeat.data(), C * sizeof(int), hipMemcpyHostToDevice, s->st));
-    HIPCHK(hipMemcpyAsync(v->d_my, yv.data(), yv.size() * sizeof(float), hipMemcpyHostToDevice, s->st));
-    if (!node_range.empty())
-        HIPCHK(hipMemcpyAsync(v->d_mrg, node_range.data(), node_range.size() * sizeof(int2), hipMemcpyHostToDevice, s->st));
-    launch_bow_best2(s->st, s->d_desc, d_sets, kcap, C, v->d_my, d_slot_of, v->d_mrg, d_node_feats, d_nfeat, v->d_mtab);
+    int *d_slot_of = v->d_mi, *d_node_feats = d_slot_of + (size_t)nimg * kcap, *d_nfeat = d_node_feats + (size_t)nimg * kcap, *d_rgbase = d_nfeat + nimg;
+    HIPCHK(hipMemcpyAsync(d_slot_of, h_slot_of.data(), h_slot_of.size() * sizeof(int), hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(d_node_feats, h_node_feats.data(), h_node_feats.size() * sizeof(int), hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(d_nfeat, h_nfeat.data(), nimg * sizeof(int), hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(d_rgbase, h_rgbase.data(), (nframes + 1) * sizeof(int), hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(v->d_my, h_yv.data(), h_yv.size() * sizeof(float), hipMemcpyHostToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(v->d_mrg, h_rg.data(), h_rg.size() * sizeof(int2), hipMemcpyHostToDevice, s->st));
+    launch_bow_best2(s->st, s->d_desc, img0, kcap, C, nframes, v->d_my, d_slot_of, v->d_mrg, d_rgbase, d_node_feats, d_nfeat, v->d_mtab);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(v->h_mtab, v->d_mtab, tab_n * sizeof(int4), hipMemcpyDeviceToHost, s->st));
+    if (tab_n) HIPCHK(hipMemcpyAsync(v->h_mtab, v->d_mtab, tab_n * sizeof(int4), hipMemcpyDeviceToHost, s->st));
     HIPCHK(hipStreamSynchronize(s->st));   // also covers the pageable host vectors above
-    const int4 *tab = v->h_mtab;
-    T4 = now();
+    const auto T3 = now();
 
-    // 4. the reference's serial walk over common nodes (:647-929), reading best/second-best from the table
-    typedef std::map<uint32_t, std::vector<int32_t>>::const_iterator It;
-    std::vector<It> it(C), last(C);
-    for (int c = 0; c < C; c++) { it[c] = fvs[c].begin(); last[c] = std::prev(fvs[c].end()); }
-    std::vector<BowTrack> matches;
-    matches.reserve(10000);   // (:587)
-    std::vector<uint32_t> words_;
-    int intraMatchInd = 0;
+    // 4. per frame: the reference's serial walk over common nodes (:647-929), reading best/second-best from the table
     const uint8_t *hd = s->h_desc;
-    auto dist = [&](int ca, int fa, int cb, int fb) {
-        return mcorb_hamming256(hd + ((size_t)(frame * C + ca) * kcap + fa) * 32, hd + ((size_t)(frame * C + cb) * kcap + fb) * 32);
-    };
-    for (;;) {
-        bool end = true;   // checkItersEnd (:569-575)
-        for (int c = 0; c < C; c++) end = end && it[c]->first >= last[c]->first;
-        if (end) break;
-        uint32_t min_val = 0x7ffffffeu;
+    R.pool->parallel_for(nframes, [&](int f, int) {
+        BowFrameOut &out = s->bow[frame0 + f];
+        out.tracks.clear(); out.n_rays.clear(); out.words.clear();
+        const FrameTables &F = ft[f];
+        if (F.empty) return;
+        const int4 *tab = v->h_mtab + (size_t)f * npairs * kcap;
+        std::vector<int> it(C, 0), last(C);
+        for (int c = 0; c < C; c++) last[c] = (int)F.fv[c].size() - 1;   // std::prev(end()): the last node is never visited (reference quirk)
+        std::vector<BowTrack> matches;
+        matches.reserve(10000);   // (:587)
+        int intraMatchInd = 0;
+        auto dist = [&](int ca, int fa, int cb, int fb) {
+            return mcorb_hamming256(hd + ((size_t)(img0 + f * C + ca) * kcap + fa) * 32, hd + ((size_t)(img0 + f * C + cb) * kcap + fb) * 32);
+        };
         std::vector<int> selected;
-        for (int c = 0; c < C; c++) {
-            const uint32_t w = it[c] == last[c] ? 0x7fffffffu : it[c]->first;
-            if (w < min_val) { min_val = w; selected.clear(); selected.push_back(c); }
-            else if (w == min_val) selected.push_back(c);
-        }
-        std::vector<std::vector<int>> matchedFlags(selected.size());
-        for (size_t i = 0; i < selected.size(); i++) matchedFlags[i].assign(it[selected[i]]->second.size(), -1);
-        if (selected.size() >= 2) {
-            for (int i = 0; i < (int)selected.size() - 1; i++) {
-                const int cam1 = selected[i];
-                const std::vector<int32_t> &feat_cam1 = it[cam1]->second;
-                for (int a = 0; a < (int)feat_cam1.size(); a++) {
-                    bool foundMatch = false;
-                    if (matchedFlags[i][a] != -1) continue;
-                    BowTrack temp;
-                    for (int tt = 0; tt < C; tt++) temp.matchIndex[tt] = -1;
-                    temp.matchIndex[cam1] = feat_cam1[a];
-                    temp.n_rays = 1;
-                    matches.push_back(temp);
-                    matchedFlags[i][a] = intraMatchInd;
-                    bool updateOnce = true;
-                    for (int j = i + 1; j < (int)selected.size(); j++) {
-                        const int cam2 = selected[j];
-                        const std::vector<int32_t> &feat_cam2 = it[cam2]->second;
-                        const int4 t = tab[((size_t)cam1 * kcap + feat_cam1[a]) * C + cam2];
-                        const int best_j_now = t.x;
-                        const double best_dist_1 = t.x < 0 ? 1e9 : (double)t.y;
-                        const double best_dist_2 = t.z == 0x7fffffff ? 1e9 : (double)t.z;
-                        if (best_dist_1 <= TH_LOW && best_dist_1 / best_dist_2 <= max_neighbor_ratio) {
-                            const int existing = matchedFlags[j][best_j_now];
-                            if (existing == intraMatchInd) continue;
-                            if (existing == -1) {
-                                matches[intraMatchInd].matchIndex[cam2] = feat_cam2[best_j_now];
-                                matches[intraMatchInd].n_rays++;
-                                matchedFlags[j][best_j_now] = intraMatchInd;
-                                foundMatch = true;
-                            } else {
-                                const int old_cam1 = matches[existing].matchIndex[cam1];
-                                if (old_cam1 == -1) {
-                                    if (updateOnce) updateOnce = false;
-                                    else continue;
-                                    bool update_match = true;
-                                    int tmp[MCORB_MAX_CAMS];
-                                    for (int tt = 0; tt < C; tt++) tmp[tt] = matches[existing].matchIndex[tt];
-                                    int inc = 0;
-                                    for (int tt = 0; tt < C; tt++) {
-                                        if (matches[intraMatchInd].matchIndex[tt] != -1) {
-                                            if (matches[existing].matchIndex[tt] != -1) { update_match = false; break; }
-                                            tmp[tt] = matches[intraMatchInd].matchIndex[tt];
-                                            inc++;
-                                        }
-                                    }
-                                    if (update_match) {
-                                        for (int tt = 0; tt < C; tt++) matches[existing].matchIndex[tt] = tmp[tt];
-                                        matches[existing].n_rays += inc;
-                                        matchedFlags[i][a] = existing;
-                                        intraMatchInd = existing;
-                                        foundMatch = true;
-                                        matches.pop_back();
-                                    }
-                                    continue;
-                                }
-                                const double d = dist(cam1, old_cam1, cam2, feat_cam2[best_j_now]);
-                                if (best_dist_1 < d) {
-                                    matches[existing].matchIndex[cam2] = -1;
-                                    matches[existing].n_rays--;
+        std::vector<std::vector<int>> matchedFlags;
+        for (;;) {
+            bool end = true;   // checkItersEnd (:569-575)
+            for (int c = 0; c < C; c++) end = end && F.fv[c][it[c]].node >= F.fv[c][last[c]].node;
+            if (end) break;
+            uint32_t min_val = 0x7ffffffeu;
+            selected.clear();
+            for (int c = 0; c < C; c++) {
+                const uint32_t w = it[c] == last[c] ? 0x7fffffffu : F.fv[c][it[c]].node;
+                if (w < min_val) { min_val = w; selected.clear(); selected.push_back(c); }
+                else if (w == min_val) selected.push_back(c);
+            }
+            matchedFlags.assign(selected.size(), std::vector<int>());
+            for (size_t i = 0; i < selected.size(); i++) matchedFlags[i].assign(F.fv[selected[i]][it[selected[i]]].cnt, -1);
+            if (selected.size() >= 2) {
+                for (int i = 0; i < (int)selected.size() - 1; i++) {
+                    const int cam1 = selected[i];
+                    const FvRun &run1 = F.fv[cam1][it[cam1]];
+                    const int32_t *feat_cam1 = F.feats[cam1].data() + run1.beg;
+                    for (int a = 0; a < run1.cnt; a++) {
+                        bool foundMatch = false;
+                        if (matchedFlags[i][a] != -1) continue;
+                        BowTrack temp;
+                        for (int tt = 0; tt < C; tt++) temp.matchIndex[tt] = -1;
+                        temp.matchIndex[cam1] = feat_cam1[a];
+                        temp.n_rays = 1;
+                        matches.push_back(temp);
+                        matchedFlags[i][a] = intraMatchInd;
+                        bool updateOnce = true;
+                        for (int j = i + 1; j < (int)selected.size(); j++) {
+                            const int cam2 = selected[j];
+                            const int32_t *feat_cam2 = F.feats[cam2].data() + F.fv[cam2][it[cam2]].beg;
+                            const int4 t = tab[(size_t)pair_of(C, cam1, cam2) * kcap + feat_cam1[a]];
+                            const int best_j_now = t.x;
+                            const double best_dist_1 = t.x < 0 ? 1e9 : (double)t.y;
+                            const double best_dist_2 = t.z == 0x7fffffff ? 1e9 : (double)t.z;
+                            if (best_dist_1 <= TH_LOW && best_dist_1 / best_dist_2 <= max_neighbor_ratio) {
+                                const int existing = matchedFlags[j][best_j_now];
+                                if (existing == intraMatchInd) continue;
+                                if (existing == -1) {
                                     matches[intraMatchInd].matchIndex[cam2] = feat_cam2[best_j_now];
                                     matches[intraMatchInd].n_rays++;
                                     matchedFlags[j][best_j_now] = intraMatchInd;
                                     foundMatch = true;
+                                } else {
+                                    const int old_cam1 = matches[existing].matchIndex[cam1];
+                                    if (old_cam1 == -1) {
+                                        if (updateOnce) updateOnce = false;
+                                        else continue;
+                                        bool update_match = true;
+                                        int tmp[MCORB_MAX_CAMS];
+                                        for (int tt = 0; tt < C; tt++) tmp[tt] = matches[existing].matchIndex[tt];
+                                        int inc = 0;
+                                        for (int tt = 0; tt < C; tt++) {
+                                            if (matches[intraMatchInd].matchIndex[tt] != -1) {
+                                                if (matches[existing].matchIndex[tt] != -1) { update_match = false; break; }
+                                                tmp[tt] = matches[intraMatchInd].matchIndex[tt];
+                                                inc++;
+                                            }
+                                        }
+                                        if (update_match) {
+                                            for (int tt = 0; tt < C; tt++) matches[existing].matchIndex[tt] = tmp[tt];
+                                            matches[existing].n_rays += inc;
+                                            matchedFlags[i][a] = existing;
+                                            intraMatchInd = existing;
+                                            foundMatch = true;
+                                            matches.pop_back();
+                                        }
+                                        continue;
+                                    }
+                                    const double d = dist(cam1, old_cam1, cam2, feat_cam2[best_j_now]);
+                                    if (best_dist_1 < d) {
+                                        matches[existing].matchIndex[cam2] = -1;
+                                        matches[existing].n_rays--;
+                                        matches[intraMatchInd].matchIndex[cam2] = feat_cam2[best_j_now];
+                                        matches[intraMatchInd].n_rays++;
+                                        matchedFlags[j][best_j_now] = intraMatchInd;
+                                        foundMatch = true;
+                                    }
                                 }
                             }
                         }
-                    }
-                    if (foundMatch) {
-                        words_.push_back(it[selected[0]]->first);
-                        intraMatchInd = (int)matches.size();
-                    } else {
-                        matches.pop_back();
-                        matchedFlags[i][a] = -1;
+                        if (foundMatch) {
+                            out.words.push_back(F.fv[selected[0]][it[selected[0]]].node);
+                            intraMatchInd = (int)matches.size();
+                        } else {
+                            matches.pop_back();
+                            matchedFlags[i][a] = -1;
+                        }
                     }
                 }
             }
+            for (int c : selected) ++it[c];
         }
-        for (int c : selected) ++it[c];
-    }
+        out.tracks.resize(matches.size() * C);
+        out.n_rays.resize(matches.size());
+        for (size_t m = 0; m < matches.size(); m++) {
+            for (int c = 0; c < C; c++) out.tracks[m * C + c] = matches[m].matchIndex[c];
+            out.n_rays[m] = matches[m].n_rays;
+        }
+    }, R.pool_threads + s->index);
+    s->bow_frames_done = std::max(s->bow_frames_done, frame0 + nframes);
     if (prof)
-        fprintf(stderr, "[mcorb host prof] match_bow: descend+sync %.0f us, assemble %.0f, tables %.0f, best2+copy %.0f, replay %.0f\n",
-                us(T0, T1), us(T1, T2), us(T2, T3), us(T3, T4), us(T4, now()));
-    if (ntracks_out) *ntracks_out = (int)matches.size();
-    if (nwords_out) *nwords_out = (int)words_.size();
-    if ((int)matches.size() > cap_tracks || (words && (int)words_.size() > cap_words)) { set_error("match_bow: output too small"); return MCORB_E_CAP; }
-    for (size_t m = 0; m < matches.size(); m++) {
-        for (int c = 0; c < C; c++) tracks[m * C + c] = matches[m].matchIndex[c];
-        if (n_rays) n_rays[m] = matches[m].n_rays;
-    }
-    if (words) for (size_t w = 0; w < words_.size(); w++) words[w] = words_[w];
+        fprintf(stderr, "[mcorb host prof] match_bow x%d frames: descend+sync %.0f us, feature vectors + tables %.0f, best2+copy %.0f, replay %.0f\n",
+                nframes, us(T0, T1), us(T1, T2), us(T2, T3), us(T3, now()));
     return MCORB_OK;
+}
+
+extern "C" int mcorb_rig_get_bow_tracks(mcorb_rig *r, int slot, int frame, int32_t *tracks, int32_t *n_rays, int cap_tracks,
+                                        int *ntracks_out, uint32_t *words, int cap_words, int *nwords_out)
+{
+    if (ntracks_out) *ntracks_out = 0;
+    if (nwords_out) *nwords_out = 0;
+    if (!r || slot < 0 || slot >= (int)r->rig.slots.size()) { set_error("bow tracks: bad argument"); return MCORB_E_ARG; }
+    Slot *s = r->rig.slots[slot];
+    if (frame < 0 || frame >= (int)s->bow.size() || frame >= s->bow_frames_done) { set_error("bow tracks: frame not matched"); return MCORB_E_STATE; }
+    const BowFrameOut &o = s->bow[frame];
+    const int C = r->rig.ncams, n = (int)o.n_rays.size();
+    if (ntracks_out) *ntracks_out = n;
+    if (nwords_out) *nwords_out = (int)o.words.size();
+    if (n > cap_tracks || (words && (int)o.words.size() > cap_words) || (n && !tracks)) { set_error("bow tracks: output too small"); return MCORB_E_CAP; }
+    if (n) memcpy(tracks, o.tracks.data(), (size_t)n * C * sizeof(int32_t));
+    if (n_rays && n) memcpy(n_rays, o.n_rays.data(), (size_t)n * sizeof(int32_t));
+    if (words && !o.words.empty()) memcpy(words, o.words.data(), o.words.size() * sizeof(uint32_t));
+    return MCORB_OK;
+}
+
+// one frame, raw keypoint rows: the round-1 entry point
+extern "C" int mcorb_rig_match_bow(mcorb_rig *r, int slot, int frame, mcorb_vocab *v, int levelsup, double max_neighbor_ratio,
+                                   int32_t *tracks, int32_t *n_rays, int cap_tracks, int *ntracks_out, uint32_t *words,
+                                   int cap_words, int *nwords_out)
+{
+    if (ntracks_out) *ntracks_out = 0;
+    if (nwords_out) *nwords_out = 0;
+    if (!tracks) { set_error("match_bow: bad argument"); return MCORB_E_ARG; }
+    const int st = mcorb_rig_match_bow_frames(r, slot, frame, 1, v, levelsup, max_neighbor_ratio, nullptr);
+    if (st != MCORB_OK) return st;
+    return mcorb_rig_get_bow_tracks(r, slot, frame, tracks, n_rays, cap_tracks, ntracks_out, words, cap_words, nwords_out);
 }

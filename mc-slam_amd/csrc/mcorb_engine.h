@@ -86,6 +86,20 @@ struct Job {
 
 class Rig;
 
+// computeIntraMatches(matches, words_) of one frame (mcorb_rig_match_bow_frames): tracks (ncams ints each), their n_rays, words_
+struct BowFrameOut {
+    std::vector<int32_t> tracks, n_rays;
+    std::vector<uint32_t> words;
+};
+
+// transform() of one image (mcorb_rig_transform_images): BowVector as sorted (word id, value) lists, FeatureVector as
+// node ids + offsets into the feature list
+struct BowImageOut {
+    std::vector<uint32_t> bow_ids, fv_nodes;
+    std::vector<double> bow_vals;
+    std::vector<int32_t> fv_offsets, fv_feats;
+};
+
 struct Slot {
     Rig *rig = nullptr;
     int index = 0;
@@ -138,6 +152,10 @@ struct Slot {
     std::vector<std::vector<uint32_t>> m_idx1, m_idx2;   // per pair
     std::vector<std::vector<int32_t>> tracks;            // per frame, ncams ints per track
     std::vector<int> mergeable;
+    std::vector<BowFrameOut> bow;   // per frame
+    int bow_frames_done = 0;
+    std::vector<BowImageOut> bowvec;   // per image
+    std::vector<uint8_t> bowvec_ok;
     float timing[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<int> match_sets, match_counts;   // per (frame, cam) of the last match: set index, descriptor count
     bool match_external = false;

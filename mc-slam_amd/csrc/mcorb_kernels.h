@@ -39,8 +39,10 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
                  int kcap, void *expanded, int *lcounts, uint2 *part, float dist_thresh, float ratio, KnnRow *out, uint32_t *mlist,
                  int *mcount, hipEvent_t ev_exp, hipEvent_t ev_mid);   // events (optional): after k_expand, after k_knn2
 
-void launch_bow_best2(hipStream_t st, const uint8_t *desc, const int *sets, int kcap, int ncams, const float *yv,
-                      const int *slot_of, const int2 *node_range, const int *node_feats, const int *nfeat, int4 *out);
+// all frames [0, nframes) of a batch whose first image is img0 of `desc` (kcap-strided sets); tables indexed by the
+// batch-local image index f * ncams + c (see k_bow_best2)
+void launch_bow_best2(hipStream_t st, const uint8_t *desc, int img0, int kcap, int ncams, int nframes, const float *yv,
+                      const int *slot_of, const int2 *node_range, const int *rg_base, const int *node_feats, const int *nfeat, int4 *out);
 void launch_bow_descend(hipStream_t st, const uint8_t *desc, int n, const int *child_start, const int *child_count,
                         const void *child_desc, const int *child_id, const int *word_id, const double *weight, int nid_level,
                         BowRes *out);

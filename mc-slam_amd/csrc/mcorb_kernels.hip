@@ -1244,30 +1244,38 @@ __global__ __launch_bounds__(256) void k_bow_descend(const uint8_t *__restrict__
 // and second-best Hamming distance among c2's features that fell into the same vocabulary node, skipping
 // candidates whose row differs by 50 px or more; strict '<' so the first minimum wins.  The serial
 // track bookkeeping that consumes this table stays on the host.
+// All frames of a batch in one launch: blockIdx.z = frame, blockIdx.y = camera pair (c1 < c2).  Per frame f the
+// index tables are laid out for image index m = f * ncams + c: slot_of / node_feats / yv at m * kcap,
+// node_range at (rg_base[f] + slot) * ncams + c; out at ((f * npairs + pair) * kcap + a).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bow_best2(const uint8_t *__restrict__ desc, const int *__restrict__ sets, int kcap, int ncams,
+__global__ __launch_bounds__(256) void k_bow_best2(const uint8_t *__restrict__ desc, int img0, int kcap, int ncams,
                                                    const float *__restrict__ yv, const int *__restrict__ slot_of,
-                                                   const int2 *__restrict__ node_range, const int *__restrict__ node_feats,
-                                                   const int *__restrict__ nfeat, int4 *__restrict__ out)
+                                                   const int2 *__restrict__ node_range, const int *__restrict__ rg_base,
+                                                   const int *__restrict__ node_feats, const int *__restrict__ nfeat,
+                                                   int4 *__restrict__ out)
 {
     const int a = blockIdx.x * 256 + threadIdx.x;
-    const int c1 = blockIdx.y, c2 = blockIdx.z;
-    if (c2 <= c1 || a >= nfeat[c1]) return;
+    const int f = blockIdx.z, npairs = ncams * (ncams - 1) / 2;
+    int c1 = 0, rem = blockIdx.y;   // pair index -> (c1, c2), pairs in (0,1), (0,2), .., (1,2), .. order
+    while (rem >= ncams - 1 - c1) { rem -= ncams - 1 - c1; c1++; }
+    const int c2 = c1 + 1 + rem;
+    const int m1 = f * ncams + c1, m2 = f * ncams + c2;
+    if (a >= nfeat[m1]) return;
     int4 r = int4{-1, 0x7fffffff, 0x7fffffff, 0};
-    const int slot = slot_of[(size_t)c1 * kcap + a];
+    const int slot = slot_of[(size_t)m1 * kcap + a];
     if (slot >= 0) {
-        const int2 rg = node_range[(size_t)slot * ncams + c2];
-        const ulonglong4 q = *reinterpret_cast<const ulonglong4 *>(desc + ((size_t)sets[c1] * kcap + a) * 32);
-        const float y1 = yv[(size_t)c1 * kcap + a];
+        const int2 rg = node_range[(size_t)(rg_base[f] + slot) * ncams + c2];
+        const ulonglong4 q = *reinterpret_cast<const ulonglong4 *>(desc + ((size_t)(img0 + m1) * kcap + a) * 32);
+        const float y1 = yv[(size_t)m1 * kcap + a];
         for (int j = 0; j < rg.y; j++) {
-            const int b = node_feats[(size_t)c2 * kcap + rg.x + j];
-            if (fabsf(__fsub_rn(y1, yv[(size_t)c2 * kcap + b])) >= 50.f) continue;
-            const int d = (int)hamming256(q, *reinterpret_cast<const ulonglong4 *>(desc + ((size_t)sets[c2] * kcap + b) * 32));
+            const int b = node_feats[(size_t)m2 * kcap + rg.x + j];
+            if (fabsf(__fsub_rn(y1, yv[(size_t)m2 * kcap + b])) >= 50.f) continue;
+            const int d = (int)hamming256(q, *reinterpret_cast<const ulonglong4 *>(desc + ((size_t)(img0 + m2) * kcap + b) * 32));
             if (d < r.y) { r.x = j; r.z = r.y; r.y = d; }
             else if (d < r.z) r.z = d;
         }
     }
-    out[((size_t)c1 * kcap + a) * ncams + c2] = r;
+    out[((size_t)f * npairs + blockIdx.y) * kcap + a] = r;
 }
 
 // ---------------------------------------------------------------------------
@@ -1376,11 +1384,12 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
                        mcount);
 }
 
-void launch_bow_best2(hipStream_t st, const uint8_t *desc, const int *sets, int kcap, int ncams, const float *yv,
-                      const int *slot_of, const int2 *node_range, const int *node_feats, const int *nfeat, int4 *out)
+void launch_bow_best2(hipStream_t st, const uint8_t *desc, int img0, int kcap, int ncams, int nframes, const float *yv,
+                      const int *slot_of, const int2 *node_range, const int *rg_base, const int *node_feats, const int *nfeat, int4 *out)
 {
-    dim3 grid((kcap + 255) / 256, ncams, ncams);
-    hipLaunchKernelGGL(k_bow_best2, grid, dim3(256), 0, st, desc, sets, kcap, ncams, yv, slot_of, node_range, node_feats, nfeat, out);
+    if (ncams < 2 || nframes < 1) return;
+    dim3 grid((kcap + 255) / 256, ncams * (ncams - 1) / 2, nframes);
+    hipLaunchKernelGGL(k_bow_best2, grid, dim3(256), 0, st, desc, img0, kcap, ncams, yv, slot_of, node_range, rg_base, node_feats, nfeat, out);
 }
 
 void launch_bow_descend(hipStream_t st, const uint8_t *desc, int n, const int *child_start, const int *child_count,

@@ -35,16 +35,18 @@ def full_vocabulary(k=10, L=6, seed=1):
 
 def main():
     import mcorb
-    C, W, H, N = 4, 1280, 720, 2000
+    C, W, H, N, F = 4, 1280, 720, 2000, 32
     t0 = time.perf_counter()
     v = full_vocabulary()
     voc = mcorb.ORBVocabulary().create(**v)
     t_build = time.perf_counter() - t0
-    rig = mcorb.Rig(C, W, H, 1, 1, nfeatures=N)
-    rig.upload([mcorb.synth_rig_frame(3, C, c, W, H) for c in range(C)])
-    rig.extract(C)
-    tt, tm = [], []
-    for it in range(30):
+    rig = mcorb.Rig(C, W, H, F, 1, nfeatures=N)
+    rig.upload([mcorb.synth_rig_frame(f, C, c, W, H) for f in range(F) for c in range(C)])
+    rig.extract(F * C)
+    L = voc.L_
+    tt, tm, bt, bm = [], [], [], []
+    for it in range(20):
+        # one frame at a time (how a per-frame caller drives it)
         t0 = time.perf_counter()
         for c in range(C):
             voc.transform_rig_image(rig, c, levelsup=4)
@@ -52,10 +54,21 @@ def main():
         tr, nr, words = voc.match_rig_frame(rig, 0, levelsup=4)
         t2 = time.perf_counter()
         tt.append(t1 - t0); tm.append(t2 - t1)
+        # all 32 frames of the slot per call (the C entry points only: reading the results back through ctypes is the
+        # caller's cost and is not part of the figure)
+        t0 = time.perf_counter()
+        rc = L.mcorb_rig_transform_images(rig.h_rig, 0, 0, F * C, voc.h, 4)
+        t1 = time.perf_counter()
+        rc |= L.mcorb_rig_match_bow_frames(rig.h_rig, 0, 0, F, voc.h, 4, 0.85, None)
+        t2 = time.perf_counter()
+        assert rc == 0
+        bt.append((t1 - t0) / F); bm.append((t2 - t1) / F)
     out = {"vocabulary": "synthetic k=10 L=6, %d nodes" % len(v["parent"]), "vocab_upload_s": round(t_build, 2),
            "transform_ms_per_rig_frame": round(float(np.median(tt[5:])) * 1e3, 3),
-           "bow_guided_match_ms_per_rig_frame": round(float(np.median(tm[5:])) * 1e3, 3), "tracks": int(len(tr)),
-           "keypoints_per_camera": int(len(rig.features(0)[1]))}
+           "bow_guided_match_ms_per_rig_frame": round(float(np.median(tm[5:])) * 1e3, 3),
+           "batched_32_frames": {"transform_ms_per_rig_frame": round(float(np.median(bt[5:])) * 1e3, 4),
+                                 "bow_guided_match_ms_per_rig_frame": round(float(np.median(bm[5:])) * 1e3, 4)},
+           "tracks": int(len(tr)), "keypoints_per_camera": int(len(rig.features(0)[1]))}
     print(json.dumps(out))
 
 

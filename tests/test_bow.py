@@ -137,6 +137,76 @@ def test_bow_guided_intra_matches(C, k, L, levelsup):
     rig.close()
 
 
+@pytest.mark.gpu
+def test_bow_batched_frames_transform_and_undistorted_rows():
+    """All frames of a slot in one call (mcorb_rig_transform_images / mcorb_rig_match_bow_frames), and the |dy| < 50 gate
+    reading the caller's UNDISTORTED rows (image_kps_undist, MultiCameraFrame.cpp:708-716) instead of the raw ones."""
+    import mcorb
+    C, W, H, N, F = 3, 640, 480, 800, 3
+    rig = mcorb.Rig(C, W, H, F, 1, nfeatures=N)
+    rig.upload([mcorb.synth_rig_frame(f, C, c, W, H) for f in (2, 5, 9) for c in range(C)])
+    rig.extract(F * C)
+    v = O.make_vocabulary(10, 4, seed=3)
+    voc = mcorb.ORBVocabulary().create(**v)
+    feats = [rig.features(m) for m in range(F * C)]
+    got_t = voc.transform_rig_images(rig, 0, F * C, levelsup=2)
+    for m in range(F * C):
+        _same(O.bow_transform(v, feats[m][2], 2), got_t[m])
+    fvs = [O.bow_transform(v, f[2], 2)[1] for f in feats]
+    # raw rows
+    got = voc.match_rig_frames(rig, 0, F, levelsup=2)
+    for f in range(F):
+        sl = slice(f * C, (f + 1) * C)
+        otr, onr, ow = O.intra_matches_bow([x[2] for x in feats[sl]], [x[1]["y"] for x in feats[sl]], fvs[sl])
+        assert len(otr) > 30
+        assert np.array_equal(got[f][0], otr) and np.array_equal(got[f][1], onr) and np.array_equal(got[f][2], ow), "frame %d" % f
+    # a non-identity undistortion: rows bent by up to 45 px, differently per camera, so that the gate decides differently
+    yu = [(x[1]["y"] + np.float32(45.0) * np.sin(x[1]["x"] / np.float32(37.0) + m)).astype(np.float32) for m, x in enumerate(feats)]
+    got_u = voc.match_rig_frames(rig, 1, 2, levelsup=2, y_undist=yu)      # frames 1..2 only: index = frame * C + cam of the slot
+    changed = False
+    for k, f in enumerate((1, 2)):
+        sl = slice(f * C, (f + 1) * C)
+        otr, onr, ow = O.intra_matches_bow([x[2] for x in feats[sl]], yu[sl], fvs[sl])
+        assert np.array_equal(got_u[k][0], otr) and np.array_equal(got_u[k][1], onr) and np.array_equal(got_u[k][2], ow), "undist frame %d" % f
+        changed |= not (got_u[k][0].shape == got[f][0].shape and np.array_equal(got_u[k][0], got[f][0]))
+    assert changed, "the bent rows should change at least one frame's tracks (else the test does not see the gate)"
+    # the single-frame entry point still answers with the raw rows
+    tr, nr, words = voc.match_rig_frame(rig, 2, levelsup=2)
+    assert np.array_equal(tr, got[2][0]) and np.array_equal(nr, got[2][1]) and np.array_equal(words, got[2][2])
+    rig.close()
+
+
+@pytest.mark.gpu
+def test_bow_config3_full_size_vocabulary():
+    """BASELINE configs[3] at its stated size: 4-cam 1280x720 @2000 keypoints with a k = 10, L = 6 vocabulary (1 111 110
+    nodes, ORB-SLAM's shape; synthetic, the file is not part of the reference): transform() of every camera and the BoW-guided
+    computeIntraMatches of two frames against the oracle."""
+    import sys
+    import mcorb
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts"))
+    from bow_rate import full_vocabulary
+    C, W, H, N, F = 4, 1280, 720, 2000, 2
+    v = full_vocabulary(10, 6, seed=1)
+    assert len(v["parent"]) == 1111110
+    voc = mcorb.ORBVocabulary().create(**v)
+    rig = mcorb.Rig(C, W, H, F, 1, nfeatures=N)
+    rig.upload([mcorb.synth_rig_frame(f, C, c, W, H) for f in (3, 4) for c in range(C)])
+    rig.extract(F * C)
+    feats = [rig.features(m) for m in range(F * C)]
+    got_t = voc.transform_rig_images(rig, 0, F * C, levelsup=4)
+    ora_t = [O.bow_transform(v, x[2], 4) for x in feats]
+    for m in range(F * C):
+        _same(ora_t[m], got_t[m])
+        assert len(got_t[m][0][0]) > 1500                     # ~2000 descriptors land on ~2000 of 10^6 words
+    got = voc.match_rig_frames(rig, 0, F, levelsup=4)
+    for f in range(F):
+        sl = slice(f * C, (f + 1) * C)
+        otr, onr, ow = O.intra_matches_bow([x[2] for x in feats[sl]], [x[1]["y"] for x in feats[sl]], [t[1] for t in ora_t[sl]])
+        assert len(otr) > 200
+        assert np.array_equal(got[f][0], otr) and np.array_equal(got[f][1], onr) and np.array_equal(got[f][2], ow), "frame %d" % f
+    rig.close()
+
+
 def _kat_descs():
     z = np.zeros(32, np.uint8)
     a1 = z.copy(); a1[:10] = 0xFF                       # 80 bits away from zero
