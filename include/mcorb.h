@@ -294,6 +294,40 @@ int mcorb_rig_get_bow_tracks(mcorb_rig *r, int slot, int frame, int32_t *tracks,
                              int *ntracks_out, uint32_t *words, int cap_words, int *nwords_out);
 
 /* ------------------------------------------------------------------------- */
+/* FrontEnd::obtainLfFeatures (MCSlam/src/FrontEnd.cpp:213-593): the consumer  */
+/* of the IntraMatch tracks.  Host code.                     */
+/* ------------------------------------------------------------------------- */
+/* one camera of camconfig_: K_mats_[i] (row-major 3x3) and build_Rt(R_mats_[i], t_mats_[i]) (row-major 3x4) */
+typedef struct mcorb_camera {
+    double K[9];
+    double Rt[12];
+} mcorb_camera;
+/* one entry of currentFrame->intraMatches as obtainLfFeatures leaves it: IntraMatch{matchIndex, uv_ref, mono, n_rays,
+ * matchDesc, point3D} (MultiCameraFrame.h:42-57); point3d is meaningful when mono == 0 */
+typedef struct mcorb_lf_feature {
+    int32_t match_index[MCORB_MAX_CAMS];
+    float uv_ref[2];
+    int32_t mono, n_rays;
+    double point3d[3];
+    uint8_t desc[32];
+} mcorb_lf_feature;
+/* tracks: ntracks x ncams ints (matches_map, -1 = absent) of `frame` of the slot, words (may be NULL): words_ per track;
+ * cams: ncams entries; seg_masks (may be NULL, or NULL per camera = all zero): per camera a float image with `seg_stride`
+ * floats per row, a view is dropped where the mask at the RAW keypoint is >= 0.7 (:262-270); kps_undist (may be NULL):
+ * image_kps_undist per camera (uv_ref and the response of mono features are read from it, :397-408, :497-505);
+ * total_feats: 3000 in the reference (:430).  out receives the accepted multi-view tracks in track order (triangulated with
+ * cv::sfm::triangulatePoints' DLT, kept when 0.5 < z < 40, :309) followed by the mono features in argsorte(responses, false)
+ * order (:514-521); *intramatch_size_out / *mono_size_out = lf_frame->intramatch_size / mono_size; words_fil (may be NULL)
+ * = the std::set filled at :344.  lIds is all -1 (one per output entry) and lfBoW is mcorb_vocab_transform of the output
+ * descriptors (:525).  Parity: every integer / ordering result exact; point3d and uv_ref of triangulated tracks to 1e-9
+ * relative (the SVD behind the reference's triangulation is un-vendored: unpinned). */
+int mcorb_rig_obtain_lf_features(mcorb_rig *r, int slot, int frame, const int32_t *tracks, int ntracks, const uint32_t *words,
+                                 const mcorb_camera *cams, const float *const *seg_masks, int seg_stride,
+                                 const mcorb_keypoint *const *kps_undist, int total_feats, mcorb_lf_feature *out, int cap,
+                                 int *n_out, int *intramatch_size_out, int *mono_size_out, uint32_t *words_fil, int cap_words,
+                                 int *nwords_fil_out);
+
+/* ------------------------------------------------------------------------- */
 /* Host stages exposed for the CPU test-suite (no device needed)              */
 /* ------------------------------------------------------------------------- */
 /* The engine's quad-tree selection, DistributeOctTree's equivalent (ORBextractor.cpp:554-778), run
@@ -313,6 +347,9 @@ int mcorb_host_resize_axis(int ssize, int dsize, int is_x, int32_t *quads);
 /* level geometry the engine derives for a w x h image: per level
  * {w, h, nCols, nRows, wCell, hCell}; returns MCORB_OK or MCORB_E_SIZE */
 int mcorb_host_geometry(const mcorb_params *p, int w, int h, int32_t *six_per_level);
+/* the N-view DLT triangulation of mcorb_rig_obtain_lf_features alone (cv::sfm::triangulatePoints for one point):
+ * x = nv normalised image points (x0, y0, x1, y1, ..), P = nv row-major 3x4 [R|t], 2 <= nv <= MCORB_MAX_CAMS */
+int mcorb_host_triangulate(const double *x, const double *P, int nv, double X[3]);
 
 /* ------------------------------------------------------------------------- */
 /* Synthetic input; host utility, see csrc/mcorb_synth.c       */

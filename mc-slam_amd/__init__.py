@@ -184,6 +184,48 @@ class Rig:
         return tr[:n.value].copy(), mg.value
 
     # -- intermediates (parity tests) -----------------------------------------
+    def obtain_lf_features(self, frame, tracks, K_mats, R_mats, t_mats, words=None, seg_masks=None, kps_undist=None,
+                           total_feats=3000, slot=0):
+        """FrontEnd::obtainLfFeatures (FrontEnd.cpp:213-593) for one frame of the slot: returns (features as a structured
+        array [match_index, uv_ref, mono, n_rays, point3d, desc], intramatch_size, mono_size, words_fil)."""
+        Cn = self.ncams
+        tracks = np.ascontiguousarray(tracks, np.int32).reshape(-1, Cn)
+        cams = (_lib.Camera * Cn)()
+        for c in range(Cn):
+            K = np.asarray(K_mats[c], np.float64).reshape(3, 3)
+            Rt = np.hstack([np.asarray(R_mats[c], np.float64).reshape(3, 3), np.asarray(t_mats[c], np.float64).reshape(3, 1)])   # build_Rt
+            cams[c].K[:] = K.ravel().tolist()
+            cams[c].Rt[:] = Rt.ravel().tolist()
+        keep, segp, stride = [], None, 0
+        if seg_masks is not None:
+            segp = (C.c_void_p * Cn)()
+            for c in range(Cn):
+                if seg_masks[c] is not None:
+                    a = np.ascontiguousarray(seg_masks[c], np.float32)
+                    keep.append(a)
+                    segp[c] = a.ctypes.data
+                    stride = a.shape[1]
+        undp = None
+        if kps_undist is not None:
+            undp = (C.c_void_p * Cn)()
+            for c in range(Cn):
+                a = np.ascontiguousarray(kps_undist[c], _lib.KP_DTYPE)
+                keep.append(a)
+                undp[c] = a.ctypes.data
+        wp = None
+        if words is not None:
+            words = np.ascontiguousarray(words, np.uint32)
+            assert len(words) >= len(tracks)
+            wp = words.ctypes.data
+        cap = Cn * self.kcap + len(tracks) + 1
+        out = np.zeros(cap, _lib.LF_DTYPE)
+        wf = np.zeros(len(tracks) + 1, np.uint32)
+        n, ni, nm, nw = (C.c_int() for _ in range(4))
+        _lib.check(self.L.mcorb_rig_obtain_lf_features(self.h_rig, slot, frame, tracks.ctypes.data, len(tracks), wp, cams, segp, stride, undp,
+                                                       total_feats, out.ctypes.data, cap, C.byref(n), C.byref(ni), C.byref(nm),
+                                                       wf.ctypes.data, len(wf), C.byref(nw)))
+        return out[:n.value].copy(), ni.value, nm.value, wf[:nw.value].copy()
+
     def level_size(self, level):
         w, h = C.c_int(), C.c_int()
         _lib.check(self.L.mcorb_rig_level_size(self.h_rig, level, C.byref(w), C.byref(h)))

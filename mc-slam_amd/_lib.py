@@ -27,6 +27,14 @@ class Params(C.Structure):
                 ("reserved", C.c_int * 7)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("K", C.c_double * 9), ("Rt", C.c_double * 12)]
+
+
+LF_DTYPE = np.dtype([("match_index", "<i4", (MAX_CAMS,)), ("uv_ref", "<f4", (2,)), ("mono", "<i4"), ("n_rays", "<i4"),
+                     ("point3d", "<f8", (3,)), ("desc", "u1", (32,))])
+
+
 class McorbError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__("mcorb error %d: %s" % (code, msg))
@@ -98,8 +106,10 @@ SIGNATURES = {
     "mcorb_rig_get_transform": (_i, [_vp, _i, _i, _vp, _vp, _i, _ip, _vp, _vp, _i, _ip, _vp, _i]),
     "mcorb_rig_match_bow_frames": (_i, [_vp, _i, _i, _i, _vp, _i, C.c_double, _vp]),
     "mcorb_rig_get_bow_tracks": (_i, [_vp, _i, _i, _vp, _vp, _i, _ip, _vp, _i, _ip]),
+    "mcorb_rig_obtain_lf_features": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _ip, _ip, _ip, _vp, _i, _ip]),
     "mcorb_host_select": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i]),
     "mcorb_host_resize_axis": (_i, [_i, _i, _i, _vp]),
+    "mcorb_host_triangulate": (_i, [_vp, _vp, _i, _vp]),
     "mcorb_host_geometry": (_i, [C.POINTER(Params), _i, _i, _vp]),
     "mcorb_synth_rig_frame": (_i, [C.c_uint32, _i, _i, _i, _i, _vp, _i]),
 }

@@ -1,0 +1,259 @@
+// mcorb_lf.cpp -- FrontEnd::obtainLfFeatures (MCSlam/src/FrontEnd.cpp:213-593), SURVEY.md 8f row N3: the immediate
+// consumer of the IntraMatch tracks.  Host code: per-track view filtering by the segmentation masks (:262-270), N-view
+// triangulation (:280-307), the depth gate (:309), representative descriptor (:349, MultiCameraFrame.cpp:530-567), and the
+// response-sorted mono fill to 3000 - intramatch_size (:478-523).  The tiling / refview branches are compile-time dead in the
+// reference (`bool tiling = false; bool refview = false;`, :436-437) and are not restated.
+//
+// Integer / ordering work is exact: the same statements in the same order, and argsorte()'s std::sort (MCSlam/utils.h:21-30)
+// is called on the same sequence with the same predicate (ties between equal responses land where libstdc++'s introsort
+// puts them -- that IS the reference's order).
+// Triangulation: cv::sfm::triangulatePoints is un-vendored third-party code (opencv_contrib / libmv): two views -> the 4x4 DLT
+// design matrix, more views -> the 3n x (4+n) "x = alpha P X" design, null vector by SVD (cv::SVD::solveZ).  Restated here with
+// a one-sided Jacobi SVD in FP64: the null vector of a full-column-rank-minus-one matrix is unique up to scale, so any
+// backward-stable method returns the same point to ~1e-12 relative; parity for this step is tolerance-based (1e-9) and UNPINNED.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+#include <vector>
+
+#include "mcorb_engine.h"
+
+using namespace mcorb;
+
+namespace {
+
+// right singular vector of the smallest singular value of the m x n matrix A (row-major, m >= n): one-sided Jacobi
+// (Hestenes): rotate column pairs until all are mutually orthogonal, accumulating the rotations in V
+void null_vector(std::vector<double> &A, int m, int n, double *x)
+{
+    std::vector<double> V((size_t)n * n, 0.0);
+    for (int i = 0; i < n; i++) V[(size_t)i * n + i] = 1.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int p = 0; p < n - 1; p++)
+            for (int q = p + 1; q < n; q++) {
+                double a = 0, b = 0, c = 0;
+                for (int i = 0; i < m; i++) {
+                    const double ap = A[(size_t)i * n + p], aq = A[(size_t)i * n + q];
+                    a += ap * ap; b += aq * aq; c += ap * aq;
+                }
+                if (c == 0.0) continue;
+                off = std::max(off, fabs(c) / sqrt(std::max(a * b, 1e-300)));
+                const double zeta = (b - a) / (2.0 * c);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                for (int i = 0; i < m; i++) {
+                    const double ap = A[(size_t)i * n + p], aq = A[(size_t)i * n + q];
+                    A[(size_t)i * n + p] = cs * ap - sn * aq;
+                    A[(size_t)i * n + q] = sn * ap + cs * aq;
+                }
+                for (int i = 0; i < n; i++) {
+                    const double vp = V[(size_t)i * n + p], vq = V[(size_t)i * n + q];
+                    V[(size_t)i * n + p] = cs * vp - sn * vq;
+                    V[(size_t)i * n + q] = sn * vp + cs * vq;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    int best = 0;
+    double bn = 1e300;
+    for (int j = 0; j < n; j++) {
+        double s = 0;
+        for (int i = 0; i < m; i++) s += A[(size_t)i * n + j] * A[(size_t)i * n + j];
+        if (s < bn) { bn = s; best = j; }
+    }
+    for (int i = 0; i < n; i++) x[i] = V[(size_t)i * n + best];
+}
+
+// cv::sfm::triangulatePoints for one point seen in nv views: x = normalised image coordinates, P = 3x4 [R|t] (row-major)
+void triangulate(const double *x, const double *const *P, int nv, double X[3])
+{
+    double h[4];
+    if (nv == 2) {   // triangulateDLT
+        std::vector<double> D(16);
+        for (int i = 0; i < 4; i++) {
+            D[0 * 4 + i] = x[0] * P[0][8 + i] - P[0][0 + i];
+            D[1 * 4 + i] = x[1] * P[0][8 + i] - P[0][4 + i];
+            D[2 * 4 + i] = x[2] * P[1][8 + i] - P[1][0 + i];
+            D[3 * 4 + i] = x[3] * P[1][8 + i] - P[1][4 + i];
+        }
+        null_vector(D, 4, 4, h);
+    } else {         // triangulateNViews: [-P_i | x_i in column 4+i] (X, alpha_1..alpha_n)^T = 0
+        const int m = 3 * nv, n = 4 + nv;
+        std::vector<double> D((size_t)m * n, 0.0), sol(n);
+        for (int i = 0; i < nv; i++) {
+            for (int jj = 0; jj < 3; jj++)
+                for (int ii = 0; ii < 4; ii++) D[(size_t)(3 * i + jj) * n + ii] = -P[i][4 * jj + ii];
+            D[(size_t)(3 * i + 0) * n + 4 + i] = x[2 * i];
+            D[(size_t)(3 * i + 1) * n + 4 + i] = x[2 * i + 1];
+            D[(size_t)(3 * i + 2) * n + 4 + i] = 1.0;
+        }
+        null_vector(D, m, n, sol.data());
+        for (int i = 0; i < 4; i++) h[i] = sol[i];
+    }
+    for (int i = 0; i < 3; i++) X[i] = h[i] / h[3];   // homogeneousToEuclidean
+}
+
+}  // namespace
+
+// host-stage hook for the CPU test-suite: the triangulation alone (x: nv normalised points, P: nv row-major 3x4 matrices)
+extern "C" int mcorb_host_triangulate(const double *x, const double *P, int nv, double X[3])
+{
+    if (!x || !P || !X || nv < 2 || nv > MCORB_MAX_CAMS) return MCORB_E_ARG;
+    const double *Pp[MCORB_MAX_CAMS];
+    for (int i = 0; i < nv; i++) Pp[i] = P + 12 * i;
+    triangulate(x, Pp, nv, X);
+    return MCORB_OK;
+}
+
+extern "C" int mcorb_rig_obtain_lf_features(mcorb_rig *r, int slot, int frame, const int32_t *tracks, int ntracks,
+                                            const uint32_t *words, const mcorb_camera *cams, const float *const *seg_masks,
+                                            int seg_stride, const mcorb_keypoint *const *kps_undist, int total_feats,
+                                            mcorb_lf_feature *out, int cap, int *n_out, int *intramatch_size_out,
+                                            int *mono_size_out, uint32_t *words_fil, int cap_words, int *nwords_fil_out)
+{
+    if (n_out) *n_out = 0;
+    if (intramatch_size_out) *intramatch_size_out = 0;
+    if (mono_size_out) *mono_size_out = 0;
+    if (nwords_fil_out) *nwords_fil_out = 0;
+    if (!r || slot < 0 || slot >= (int)r->rig.slots.size() || ntracks < 0 || (ntracks && !tracks) || !cams || !out || cap < 0) {
+        set_error("obtain_lf_features: bad argument");
+        return MCORB_E_ARG;
+    }
+    Rig &R = r->rig;
+    Slot *s = R.slots[slot];
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        if (s->busy) { set_error("slot busy"); return MCORB_E_STATE; }
+    }
+    const int C = R.ncams, kcap = R.geom.kcap;
+    if (frame < 0 || (frame + 1) * C > s->nimg_done) { set_error("obtain_lf_features: frame not extracted"); return MCORB_E_STATE; }
+    const int m0 = frame * C;
+    auto KP = [&](int c) -> const std::vector<mcorb_keypoint> & { return s->kps[m0 + c]; };
+    auto KPU = [&](int c, int k) -> const mcorb_keypoint & { return kps_undist && kps_undist[c] ? kps_undist[c][k] : s->kps[m0 + c][k]; };
+    auto DESC = [&](int c, int k) -> const uint8_t * { return s->h_desc + ((size_t)(m0 + c) * kcap + k) * 32; };
+    auto seg = [&](int c, float px, float py) -> float {   // segMasks[i].at<float>(p.y, p.x): float -> int conversion truncates
+        if (!seg_masks || !seg_masks[c]) return 0.f;
+        return seg_masks[c][(size_t)(int)py * seg_stride + (int)px];
+    };
+    for (int t = 0; t < ntracks; t++)
+        for (int c = 0; c < C; c++) {
+            const int k = tracks[(size_t)t * C + c];
+            if (k < -1 || k >= (int)KP(c).size()) { set_error("obtain_lf_features: track index out of range"); return MCORB_E_ARG; }
+        }
+    std::vector<std::vector<uint8_t>> keypoint_mask(C);          // (:221-227)
+    for (int c = 0; c < C; c++) keypoint_mask[c].assign(KP(c).size(), 1);
+    std::vector<const double *> prj(C);
+    for (int c = 0; c < C; c++) prj[c] = cams[c].Rt;             // build_Rt(R, t) (:224)
+
+    std::vector<mcorb_lf_feature> intra, mono_keypoints;
+    std::vector<float> responses;
+    std::vector<uint32_t> wfil;
+    intra.reserve(3000); mono_keypoints.reserve(3000); responses.reserve(3000);
+    int intramatch_size = 0, mono_size = 0;
+    auto blank = [&]() {
+        mcorb_lf_feature f;
+        memset(&f, 0, sizeof(f));
+        for (int c = 0; c < MCORB_MAX_CAMS; c++) f.match_index[c] = -1;
+        return f;
+    };
+
+    for (int ind = 0; ind < ntracks; ind++) {                    // (:250-414)
+        mcorb_lf_feature temp = blank();
+        for (int c = 0; c < C; c++) temp.match_index[c] = tracks[(size_t)ind * C + c];
+        int view_inds[MCORB_MAX_CAMS], num_views = 0;
+        const uint8_t *descs[MCORB_MAX_CAMS];
+        for (int i = 0; i < C; i++) {
+            const int feat_ind = temp.match_index[i];
+            if (feat_ind != -1) {
+                const mcorb_keypoint &kp = KP(i)[feat_ind];
+                // `segMasks[i].at<float>(p.y, p.x) < 0.7` (:264): the float is promoted and compared with the DOUBLE 0.7, so a
+                // mask value of exactly 0.7f (0.699999988) still counts as static
+                if ((double)seg(i, kp.x, kp.y) < 0.7) {
+                    descs[num_views] = DESC(i, feat_ind);
+                    view_inds[num_views++] = i;
+                } else {
+                    temp.match_index[i] = -1;
+                }
+            }
+        }
+        if (num_views > 1) {
+            double xx[2 * MCORB_MAX_CAMS];
+            const double *PJs[MCORB_MAX_CAMS];
+            for (int ii = 0; ii < num_views; ii++) {
+                const int v = view_inds[ii];
+                const mcorb_keypoint &kp = KP(v)[temp.match_index[v]];
+                PJs[ii] = prj[v];
+                xx[2 * ii] = ((double)kp.x - cams[v].K[2]) / cams[v].K[0];          // (pt.x - cx) / fx (:291-293)
+                xx[2 * ii + 1] = ((double)kp.y - cams[v].K[5]) / cams[v].K[4];
+            }
+            double X[3];
+            triangulate(xx, PJs, num_views, X);
+            if (X[2] < 40 && X[2] > 0.5) {                       // (:309)
+                // K_mats_[0] * pt3d (:339-341): the point is taken in the reference camera's frame
+                const double *K0 = cams[0].K;
+                const double px = K0[0] * X[0] + K0[1] * X[1] + K0[2] * X[2], py = K0[3] * X[0] + K0[4] * X[1] + K0[5] * X[2],
+                             pz = K0[6] * X[0] + K0[7] * X[1] + K0[8] * X[2];
+                if (words) wfil.push_back(words[ind]);
+                uint8_t packed[MCORB_MAX_CAMS * 32];
+                for (int ii = 0; ii < num_views; ii++) memcpy(packed + 32 * ii, descs[ii], 32);
+                const int rep = mcorb_representative_desc(packed, num_views);   // computeRepresentativeDesc (:349)
+                memcpy(temp.desc, descs[rep], 32);
+                temp.point3d[0] = X[0]; temp.point3d[1] = X[1]; temp.point3d[2] = X[2];
+                temp.uv_ref[0] = (float)(px / pz);               // cv::Point2f(expected_x, expected_y)
+                temp.uv_ref[1] = (float)(py / pz);
+                temp.mono = 0;
+                temp.n_rays = num_views;
+                intra.push_back(temp);
+                intramatch_size++;
+                for (int ii = 0; ii < num_views; ii++) keypoint_mask[view_inds[ii]][temp.match_index[view_inds[ii]]] = 0;
+            }
+        } else if (num_views == 1) {                             // (:396-412)
+            const int v = view_inds[0], k = temp.match_index[v];
+            memcpy(temp.desc, descs[0], 32);
+            temp.uv_ref[0] = KPU(v, k).x; temp.uv_ref[1] = KPU(v, k).y;
+            temp.n_rays = 1;
+            temp.mono = 1;
+            mono_keypoints.push_back(temp);
+            responses.push_back(KPU(v, k).response);
+            keypoint_mask[v][k] = 0;
+        }
+    }
+    // every keypoint no track used becomes a mono candidate, camera by camera (:489-512); the segmentation test is commented
+    // out in this branch of the reference
+    for (int i = 0; i < C; i++)
+        for (int j = 0; j < (int)KP(i).size(); j++)
+            if (keypoint_mask[i][j]) {
+                mcorb_lf_feature f = blank();
+                f.match_index[i] = j;
+                memcpy(f.desc, DESC(i, j), 32);
+                f.uv_ref[0] = KPU(i, j).x; f.uv_ref[1] = KPU(i, j).y;
+                f.n_rays = 1;
+                f.mono = 1;
+                mono_keypoints.push_back(f);
+                responses.push_back(KPU(i, j).response);
+                keypoint_mask[i][j] = 0;
+            }
+    // argsorte(responses, false) (MCSlam/utils.h:21-30): std::sort of the index sequence, descending response
+    std::vector<int> sorted((int)responses.size());
+    std::iota(sorted.begin(), sorted.end(), 0);
+    std::sort(sorted.begin(), sorted.end(), [&responses](int i, int j) -> bool { return responses[i] > responses[j]; });
+    for (int i = 0; i < (int)sorted.size() && i < (total_feats - intramatch_size); ++i) {   // (:515-521)
+        intra.push_back(mono_keypoints[sorted[i]]);
+        mono_size++;
+    }
+    // words_fil is a std::set: ascending, unique
+    std::sort(wfil.begin(), wfil.end());
+    wfil.erase(std::unique(wfil.begin(), wfil.end()), wfil.end());
+
+    if (n_out) *n_out = (int)intra.size();
+    if (intramatch_size_out) *intramatch_size_out = intramatch_size;
+    if (mono_size_out) *mono_size_out = mono_size;
+    if (nwords_fil_out) *nwords_fil_out = (int)wfil.size();
+    if ((int)intra.size() > cap || (words_fil && (int)wfil.size() > cap_words)) { set_error("obtain_lf_features: output too small"); return MCORB_E_CAP; }
+    if (!intra.empty()) memcpy(out, intra.data(), intra.size() * sizeof(mcorb_lf_feature));
+    if (words_fil && !wfil.empty()) memcpy(words_fil, wfil.data(), wfil.size() * sizeof(uint32_t));
+    return MCORB_OK;
+}

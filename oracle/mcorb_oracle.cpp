@@ -1135,6 +1135,22 @@ extern "C" int orc_representative_desc(const uint8_t *descs, int n)
     return BestIdx;
 }
 
+/* argsorte(data, ascen) (MCSlam/include/MCSlam/utils.h:21-30): std::sort of the index sequence 0..n-1 by data; equal
+ * entries land where libstdc++'s introsort puts them -- that placement is part of the reference's result (the mono
+ * fill of FrontEnd::obtainLfFeatures, FrontEnd.cpp:514, sorts integer-valued FAST responses: ties are the rule) */
+#include <numeric>
+extern "C" void orc_argsorte(const float *data_in, int n, int ascen, int *indices_out)
+{
+    std::vector<float> data(data_in, data_in + n);
+    std::vector<int> indices(n);
+    std::iota(indices.begin(), indices.end(), 0);
+    if (ascen)
+        std::sort(indices.begin(), indices.end(), [&data](int i, int j) -> bool { return data[i] < data[j]; });
+    else
+        std::sort(indices.begin(), indices.end(), [&data](int i, int j) -> bool { return data[i] > data[j]; });
+    for (int i = 0; i < n; i++) indices_out[i] = indices[i];
+}
+
 /* ------------------------------------------------------------------------- */
 /* DBoW2 TemplatedVocabulary<FORB>::transform (un-vendored dependency of the        */
 /* reference, restated from the published algorithm -- call sites MultiCameraFrame.cpp:257,      */

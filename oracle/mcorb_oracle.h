@@ -118,6 +118,8 @@ int orc_get_matches_dist_ratio(const uint8_t *A, const uint32_t *iA, int nA,
                                const uint8_t *B, const uint32_t *iB, int nB,
                                double max_neighbor_ratio,
                                uint32_t *mA, uint32_t *mB, int *bookK);
+/* argsorte (MCSlam/include/MCSlam/utils.h:21-30): indices sorted by data with std::sort, ascending or descending */
+void orc_argsorte(const float *data, int n, int ascen, int *indices_out);
 /* BFMatcher(NORM_HAMMING).knnMatch(q,t,out,2) (A.7): idx/dist are nq x 2, absent = -1 */
 void orc_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int32_t *idx, int32_t *dist);
 /* MultiCameraFrame::BruteForceMatch filter, MultiCameraFrame.cpp:1060-1078 */

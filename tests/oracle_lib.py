@@ -310,6 +310,94 @@ def get_matches_dist_ratio(A, iA, B, iB, ratio=0.85):
     return mA[:n].copy(), mB[:n].copy(), bk.value
 
 
+def argsorte(data, ascen=True):
+    """argsorte (MCSlam/include/MCSlam/utils.h:21-30), std::sort tie placement included"""
+    data = np.ascontiguousarray(data, np.float32)
+    out = np.zeros(max(len(data), 1), np.int32)
+    lib().orc_argsorte(data.ctypes.data_as(C.POINTER(C.c_float)), len(data), int(bool(ascen)), out.ctypes.data_as(C.POINTER(C.c_int)))
+    return out[:len(data)]
+
+
+def obtain_lf_features(kps, descs, tracks, K_mats, R_mats, t_mats, words=None, seg_masks=None, kps_undist=None, total_feats=3000):
+    """FrontEnd::obtainLfFeatures (MCSlam/src/FrontEnd.cpp:213-593), the live branch (tiling = refview = false), restated
+    statement by statement on numpy arrays.  Triangulation: cv::sfm::triangulatePoints (un-vendored opencv_contrib) -- two views:
+    4x4 DLT design, more: the 3n x (4+n) design; null vector = numpy's SVD (LAPACK), FP64.  Returns (list of dict features,
+    intramatch_size, mono_size, sorted unique words_fil)."""
+    Cn = len(kps)
+    und = kps_undist if kps_undist is not None else kps
+    keypoint_mask = [np.ones(len(k), bool) for k in kps]
+    prj = [np.hstack([np.asarray(R_mats[i], np.float64).reshape(3, 3), np.asarray(t_mats[i], np.float64).reshape(3, 1)]) for i in range(Cn)]
+    K = [np.asarray(k, np.float64).reshape(3, 3) for k in K_mats]
+    intra, mono, responses, wfil = [], [], [], set()
+
+    def seg(i, x, y):
+        if seg_masks is None or seg_masks[i] is None:
+            return 0.0
+        return float(seg_masks[i][int(y), int(x)])     # .at<float>(p.y, p.x): float -> int truncates
+
+    intramatch_size = 0
+    for ind, row in enumerate(np.asarray(tracks, np.int32).reshape(-1, Cn)):
+        mi = [int(v) for v in row]
+        view_inds, dd = [], []
+        for i in range(Cn):
+            if mi[i] != -1:
+                kp = kps[i][mi[i]]
+                if seg(i, kp["x"], kp["y"]) < 0.7:
+                    dd.append(descs[i][mi[i]])
+                    view_inds.append(i)
+                else:
+                    mi[i] = -1
+        nv = len(view_inds)
+        if nv > 1:
+            xx = []
+            for v in view_inds:
+                kp = kps[v][mi[v]]
+                xx.append(((float(kp["x"]) - K[v][0, 2]) / K[v][0, 0], (float(kp["y"]) - K[v][1, 2]) / K[v][1, 1]))
+            if nv == 2:
+                Pl, Pr = prj[view_inds[0]], prj[view_inds[1]]
+                D = np.stack([xx[0][0] * Pl[2] - Pl[0], xx[0][1] * Pl[2] - Pl[1], xx[1][0] * Pr[2] - Pr[0], xx[1][1] * Pr[2] - Pr[1]])
+                h = np.linalg.svd(D)[2][-1]
+            else:
+                D = np.zeros((3 * nv, 4 + nv))
+                for i, v in enumerate(view_inds):
+                    D[3 * i:3 * i + 3, :4] = -prj[v]
+                    D[3 * i, 4 + i], D[3 * i + 1, 4 + i], D[3 * i + 2, 4 + i] = xx[i][0], xx[i][1], 1.0
+                h = np.linalg.svd(D)[2][-1][:4]
+            X = h[:3] / h[3]
+            if X[2] < 40 and X[2] > 0.5:
+                pr = K[0] @ X
+                if words is not None:
+                    wfil.add(int(words[ind]))
+                rep = representative_desc(np.stack(dd))
+                intra.append(dict(match_index=list(mi), uv_ref=(np.float32(pr[0] / pr[2]), np.float32(pr[1] / pr[2])), mono=0, n_rays=nv,
+                                  point3d=X, desc=dd[rep]))
+                intramatch_size += 1
+                for v in view_inds:
+                    keypoint_mask[v][mi[v]] = False
+        elif nv == 1:
+            v = view_inds[0]
+            u = und[v][mi[v]]
+            mono.append(dict(match_index=list(mi), uv_ref=(u["x"], u["y"]), mono=1, n_rays=1, point3d=np.zeros(3), desc=dd[0]))
+            responses.append(u["response"])
+            keypoint_mask[v][mi[v]] = False
+    for i in range(Cn):
+        for j in range(len(kps[i])):
+            if keypoint_mask[i][j]:
+                mi = [-1] * Cn
+                mi[i] = j
+                mono.append(dict(match_index=mi, uv_ref=(und[i][j]["x"], und[i][j]["y"]), mono=1, n_rays=1, point3d=np.zeros(3), desc=descs[i][j]))
+                responses.append(und[i][j]["response"])
+                keypoint_mask[i][j] = False
+    order = argsorte(np.array(responses, np.float32), False)
+    mono_size = 0
+    for i in range(len(order)):
+        if i >= total_feats - intramatch_size:
+            break
+        intra.append(mono[order[i]])
+        mono_size += 1
+    return intra, intramatch_size, mono_size, sorted(wfil)
+
+
 def representative_desc(descs):
     descs = np.ascontiguousarray(descs, np.uint8).reshape(-1, 32)
     return lib().orc_representative_desc(_ptr(descs), len(descs))
