@@ -112,19 +112,25 @@ static int build_vocab(int k, int L, int scoring, int weighting, const int32_t *
             child_desc.insert(child_desc.end(), desc + (size_t)(c - 1) * 32, desc + (size_t)c * 32);
         }
     }
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipMalloc((void **)&v->d_child_start, (n + 1) * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&v->d_child_count, (n + 1) * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&v->d_child_id, child_id.size() * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&v->d_child_desc, child_desc.size()));
-    HIPCHK(hipMemcpy(v->d_child_start, v->child_start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(v->d_child_count, v->child_count.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(v->d_child_id, child_id.data(), child_id.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(v->d_child_desc, child_desc.data(), child_desc.size(), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void **)&v->d_word_id, (size_t)(n + 1) * sizeof(int)));
-    HIPCHK(hipMalloc((void **)&v->d_weight, (size_t)(n + 1) * sizeof(double)));
-    HIPCHK(hipMemcpy(v->d_word_id, v->word_id.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(v->d_weight, v->weight.data(), (size_t)(n + 1) * sizeof(double), hipMemcpyHostToDevice));
+    // device copies; a failure on the way frees the half-built object (free_vocab tolerates null members)
+    auto upload = [&]() -> int {
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipMalloc((void **)&v->d_child_start, (n + 1) * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&v->d_child_count, (n + 1) * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&v->d_child_id, child_id.size() * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&v->d_child_desc, child_desc.size()));
+        HIPCHK(hipMemcpy(v->d_child_start, v->child_start.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(v->d_child_count, v->child_count.data(), (n + 1) * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(v->d_child_id, child_id.data(), child_id.size() * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(v->d_child_desc, child_desc.data(), child_desc.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void **)&v->d_word_id, (size_t)(n + 1) * sizeof(int)));
+        HIPCHK(hipMalloc((void **)&v->d_weight, (size_t)(n + 1) * sizeof(double)));
+        HIPCHK(hipMemcpy(v->d_word_id, v->word_id.data(), (size_t)(n + 1) * sizeof(int), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(v->d_weight, v->weight.data(), (size_t)(n + 1) * sizeof(double), hipMemcpyHostToDevice));
+        return MCORB_OK;
+    };
+    const int st = upload();
+    if (st != MCORB_OK) { free_vocab(v); return st; }
     *out = v;
     return MCORB_OK;
 }

@@ -473,7 +473,6 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         s->kps.resize(M);
         s->mono.assign(M, 0);
         s->sel_val.resize(M * geom.nlevels);
-        s->sel_pending = std::unique_ptr<std::atomic<int>[]>(new std::atomic<int>[M]);
         s->m_idx1.resize(npairs_max);
         s->m_idx2.resize(npairs_max);
         s->tracks.resize(max_frames);
@@ -742,23 +741,10 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     const auto t0 = std::chrono::steady_clock::now();
     const int L = geom.nlevels, nimg = j.nimg;
     std::atomic<int> bad{0};
-    // selection + assembly: one task per image.  The task body can split an image's levels into `parts` quota-balanced
-    // groups (whichever task finishes an image last assembles it), but with a single rig frame per call the extra tasks
-    // only wait for sleeping workers to wake up: measured 0.64-0.70 ms per frame with two parts against 0.55-0.60 with one.
-    const int parts = 1;
-    int part_of[kMaxLevels];
-    {
-        int load[2] = {0, 0};
-        for (int l = 0; l < L; l++) {   // levels come in descending quota: greedy assignment balances the two groups
-            const int p = parts == 2 && load[1] < load[0] ? 1 : 0;
-            part_of[l] = p;
-            load[p] += tab.quota[l];
-        }
-    }
-    for (int m = 0; m < nimg; m++) s.sel_pending[m].store(parts, std::memory_order_relaxed);
-    pool->parallel_for(nimg * parts, [&](int task, int w) {
+    // selection + assembly: one task per image.  (Splitting an image's levels over two tasks was measured slower for single
+    // rig frames -- the extra tasks only wait for sleeping workers to wake up -- and is gone.)
+    pool->parallel_for(nimg, [&](int m, int w) {
         HostProf::Scope prof_task(0);
-        const int m = task / parts, part = task - m * parts;
         const int *tb = s.tbl(m);
         const int *lo = tb + kTblLvlOff, *shp = tb + kTblShipped;
         const int *bst = tb + kTblHead;
@@ -772,18 +758,16 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
             const uint32_t *b1 = reinterpret_cast<const uint32_t *>(bst);
             const uint32_t *b2 = reinterpret_cast<const uint32_t *>(win);
             for (int l = 0; l < L; l++) {
-                if (part_of[l] != part) continue;
                 if (shp[l])
                     for (int i = lo[l], e = lo[l + 1]; i < e; i += 16) touch += c[i];
                 const int b0 = geom.lv[l].bucket0, nb = geom.lv[l].nBuckets + 1;
                 for (int i = b0; i < b0 + nb; i += 16) touch += b1[i];
                 for (int i = 2 * b0; i < 2 * (b0 + nb); i += 16) touch += b2[i];
             }
-            s.touch_sink[task & 15] = touch;   // keeps the loads alive
+            s.touch_sink[m & 15] = touch;   // keeps the loads alive
         }
         HostProf::Scope *prof_sel = new (alloca(sizeof(HostProf::Scope))) HostProf::Scope(1);
         for (int level = 0; level < L; level++) {
-            if (part_of[level] != part) continue;
             const int n = lo[level + 1] - lo[level];
             std::vector<uint32_t> &out = s.sel_val[(size_t)m * L + level];
             out.resize((size_t)tab.quota[level] + 64);
@@ -799,7 +783,6 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
             out.resize(r);
         }
         prof_sel->~Scope();
-        if (s.sel_pending[m].fetch_sub(1, std::memory_order_acq_rel) != 1) return;   // another part of this image is still running
         // assembly (ORBextractor.cpp:1103-1170): final order, lapping partition, coordinate scaling
         int total = 0;
         for (int l = 0; l < L; l++) total += (int)s.sel_val[(size_t)m * L + l].size();

@@ -147,7 +147,6 @@ struct Slot {
     std::vector<std::vector<mcorb_keypoint>> kps;   // per image
     std::vector<int> mono;
     std::vector<std::vector<uint32_t>> sel_val;     // per (image, level): retained candidates (packed), result order
-    std::unique_ptr<std::atomic<int>[]> sel_pending;   // per image: selection parts still running
     int npairs_done = 0, nframes_done = 0, nimg_done = 0;
     std::vector<std::vector<uint32_t>> m_idx1, m_idx2;   // per pair
     std::vector<std::vector<int32_t>> tracks;            // per frame, ncams ints per track
