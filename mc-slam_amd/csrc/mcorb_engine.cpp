@@ -392,6 +392,12 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     HIPCHK(hipMemcpy(d_taps, taps.data(), taps.size() * sizeof(ResizeTap), hipMemcpyHostToDevice));
     TRY(dev_alloc(&d_lut, lut.size() + 8));
     HIPCHK(hipMemcpy(d_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    {
+        std::vector<uint32_t> ft;
+        fast_tab_stride = fast_item_table(geom, ft);
+        TRY(dev_alloc(&d_fasttab, ft.size()));
+        HIPCHK(hipMemcpy(d_fasttab, ft.data(), ft.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     HIPCHK(upload_umax(tab.umax));
 
     int nthreads = p.host_threads > 0 ? p.host_threads : (int)std::thread::hardware_concurrency();
@@ -522,6 +528,7 @@ Rig::~Rig()
     for (auto *sc : scratch) delete sc;
     if (d_taps) (void)hipFree(d_taps);
     if (d_lut) (void)hipFree(d_lut);
+    if (d_fasttab) (void)hipFree(d_fasttab);
 }
 
 // An upload into a slot whose job is still running would overwrite the staging buffer and level 0 between the job's
@@ -713,7 +720,7 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
     HIPCHK(hipEventRecord(s.ev[0], s.st));
     launch_pyramid(s.st, s.d_pyr, geom, d_taps, resize_win, j.nimg);
     HIPCHK(hipEventRecord(s.ev[1], s.st));
-    launch_fast(s.st, s.d_pyr, geom, params.ini_th_fast, params.min_th_fast, s.d_cellkp, s.d_cellcnt, j.nimg);
+    launch_fast(s.st, s.d_pyr, geom, params.ini_th_fast, params.min_th_fast, d_fasttab, fast_tab_stride, s.d_cellkp, s.d_cellcnt, j.nimg);
     HIPCHK(hipEventRecord(s.ev[2], s.st));
     // compaction fills the per-image table blocks in device memory (a short kernel: it runs on the compute stream, ahead
     // of the blur); the DMA that takes the blocks to the host runs on the side stream while the blur computes.

@@ -197,6 +197,8 @@ public:
     int device = 0;
     ResizeTap *d_taps = nullptr;
     uint16_t *d_lut = nullptr;             // path-code tables of all levels (k_compact)
+    uint32_t *d_fasttab = nullptr;         // k_fast_cells' item -> LDS offset table (fast_item_table)
+    int fast_tab_stride = 0;
     SelectParams selp[kMaxLevels];         // per-level DistributeOctTree constants + bucketing depth
     int resize_win[2 * kMaxLevels] = {};   // per level: LDS window pitch, rows (see launch_pyramid)
     std::vector<Slot *> slots;

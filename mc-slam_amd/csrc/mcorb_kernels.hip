@@ -12,6 +12,7 @@
 #include "mcorb_common.h"
 #include "mcorb_kernels.h"
 #include <stdlib.h>
+#include <vector>
 
 namespace mcorb {
 
@@ -248,9 +249,10 @@ __device__ __forceinline__ void fast_cell_setup(const uint8_t *pyr, const Geom &
 
 // Work-list capacity.  A trip of pass 1 appends at most 256 entries and runs only while 256 more still fit, so the
 // list never overflows; a cell with more survivors than that (dense texture, noise) is processed in several chunks
-// (see the kernel).  512 keeps the wave's LDS at 5 KiB = 32 waves per CU; the benchmark's cells hold 80 survivors on
-// average, 250 at most.
-constexpr int kFastListCap = 512;
+// (see the kernel).  The capacity also sets the wave's LDS footprint and with it the occupancy; measured at 720p
+// (128 images): 512 entries = 5.0 KiB = 32 waves per CU: 410 us; 640: 387; 768 = 5.5 KiB = 29 waves: 380; 832: 377;
+// 896: 403; 1024 = 26 waves: 402.  The benchmark's cells hold 80 survivors on average, 250 at most.
+constexpr int kFastListCap = 768;
 
 // pass 1 over one cell, from item `item0` (a multiple of 64) until the cell is done or the list is full; returns the
 // length of the work list and advances item0
@@ -258,19 +260,19 @@ constexpr int kFastListCap = 512;
 #define EMIN __builtin_elementwise_min
 template <int TP>
 __device__ __forceinline__ int fast_pass1(const uint8_t *tile, const uint2 *cm, uint16_t *work, const FastCell &C, int T, int lane,
-                                          int &item0, int cap)
+                                          int &item0, int cap, const uint32_t *__restrict__ tab, int tabStride)
 {
-    const int ng = C.ng, items = C.hi * ng;
-    const float rng = __builtin_amdgcn_rcpf((float)ng);
-    const int q = __builtin_amdgcn_readfirstlane((int)(64.5f * rng)), rem = 64 - q * ng;   // 64 = q*ng + rem
-    // item = (row, group) in raster order, 64 consecutive items per trip: the lane's item advances by (q rows, rem groups)
-    int r = (int)(((float)(item0 + lane) + 0.5f) * rng), gi = item0 + lane - r * ng;
+    const int items = C.hi * C.ng;
+    // item = (row, group) in raster order, 64 consecutive items per trip.  Where an item lives in the LDS tile depends on
+    // (groups per row, first group) only: the host tabulated it (fast_item_table(): entry = tile byte offset | group << 16),
+    // so a trip costs one coalesced 256-byte load instead of a divide-free but 10-instruction index update per lane.
+    const uint32_t *tb = tab + (size_t)(C.ng * 2 + C.g0) * tabStride + item0 + lane;
     int nA = 0;
-    auto trip = [&](bool in) {
-        const int G = C.g0 + gi;
-        const int off = (int)__umul24((uint32_t)(in ? r + 3 : 3), (uint32_t)TP) + 4 * G;   // tile byte = work-list entry
+    auto trip = [&](uint32_t e, bool in) {
+        const int off = in ? (int)(e & 0xffffu) : 3 * TP;   // tile byte = work-list entry
+        const int G = in ? (int)(e >> 16) : TP / 4;          // column-mask entry; TP/4 is the all-zero one
         const uint32_t *p = reinterpret_cast<const uint32_t *>(tile + off);
-        const uint2 vm = cm[in ? G : TP / 4];   // 0xffff per evaluated column of the group; entry TP/4 is all-zero
+        const uint2 vm = cm[G];   // 0xffff per evaluated column of the group
         const uint32_t Cc = p[0], Cl = p[-1], Cr = p[1], Up = p[-3 * (TP / 4)], Dn = p[3 * (TP / 4)];
         const uint32_t Lf = __builtin_amdgcn_alignbyte(Cc, Cl, 1);   // px 4G-3 .. 4G
         const uint32_t Rt = __builtin_amdgcn_alignbyte(Cr, Cc, 3);   // px 4G+3 .. 4G+6
@@ -295,13 +297,15 @@ __device__ __forceinline__ int fast_pass1(const uint8_t *tile, const uint2 *cm, 
         nA += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
     };
     int i0 = item0;
+    uint32_t e = tb[0];                  // (the table is padded by 64 in-range entries past the last item)
     for (; i0 + 64 <= items && nA + 256 <= cap; i0 += 64) {   // full trips: every lane holds an item
-        trip(true);
-        gi += rem; r += q;
-        if (gi >= ng) { gi -= ng; r += 1; }
+        tb += 64;
+        const uint32_t en = tb[0];       // next trip's entries travel while this one is tested
+        trip(e, true);
+        e = en;
     }
     if (i0 < items && i0 + 64 > items && nA + 256 <= cap) {   // last trip: lanes past the end take the all-zero mask entry
-        trip(i0 + lane < items);   // (a select, not a branch: the ballots inside need the whole wave)
+        trip(e, i0 + lane < items);   // (a select, not a branch: the ballots inside need the whole wave)
         i0 += 64;
     }
     item0 = i0;
@@ -354,11 +358,11 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *lo)   // lo = &pixe
 // cells with pooled survivor lists, were measured slower: the extra LDS / SGPRs cost more occupancy than they save --
 // 443-456 us and 787 us against 431 us per 128 images.)
 // LDS of the wave: [16 B][tile, tileB][16 B][score map of ROI rows 2 .. rows-3, scB][16 B][column masks, (TP/4 + 1) x 8 B]
-// [work list, cap x 2 B] = 5 KiB at TP = 48: 32 waves per CU; <= 80 SGPRs and <= 64 VGPRs keep 8 waves per SIMD.
+// [work list, cap x 2 B] = 5.5 KiB at TP = 48: 29 waves per CU (the measured optimum); <= 80 SGPRs and <= 64 VGPRs leave 8 waves per SIMD.
 template <int TP>
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom g, int iniTh, int minTh,
-                                                   int tileB, int scB, int cap, uint32_t *__restrict__ cell_kp,
-                                                   int *__restrict__ cell_cnt)
+                                                   int tileB, int scB, int cap, const uint32_t *__restrict__ tab, int tabStride,
+                                                   uint32_t *__restrict__ cell_kp, int *__restrict__ cell_cnt)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     constexpr int NQ = TP / 16, NG = TP / 4;
@@ -445,7 +449,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 #pragma unroll 1
         for (;;) {
             const bool whole = item0 == 0;
-            const int nA = fast_pass1<TP>(tile, cm, work, C, T, lane, item0, cap);
+            const int nA = fast_pass1<TP>(tile, cm, work, C, T, lane, item0, cap, tab, tabStride);
             __syncthreads();
             if (sweep == 0) {
                 score(nA, T);
@@ -1005,18 +1009,24 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c)
     return r;
 }
 
-// kKnnStageTiles: train tiles per LDS stage (8 KiB each), double buffered
-template <int kKnnStageTiles>
-__global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint4 *__restrict__ E, const int *__restrict__ lcounts,
-                                                        const int2 *__restrict__ pairs, int kcap, int nchunks,
-                                                        uint2 *__restrict__ part)
+// kKnnStageTiles: train tiles per LDS stage (8 KiB each), double buffered.  The stages are filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers, which keeps the kernel at 4 waves per SIMD).
+// 1-D grid, XCD-aware: workgroups b and b + 8 share an XCD, so the query blocks of one (pair, chunk) unit are given ids
+// that are congruent mod 8 -- they stream the same train set and find it in their XCD's L2 after the first has fetched it.
+template <int kKnnStageTiles, int kWavesPerSimd>
+__global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const uint4 *__restrict__ E, const int *__restrict__ lcounts,
+                                                           const int2 *__restrict__ pairs, int kcap, int nchunks, int npairs,
+                                                           int qblocks, uint2 *__restrict__ part)
 {
     __shared__ __attribute__((aligned(16))) uint4 stage[2][kKnnStageTiles * kTileU4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
-    const int pair = blockIdx.z, chunk = blockIdx.y;
+    const int slot = blockIdx.x >> 3, grp = slot / qblocks;
+    const int unit = grp * 8 + (blockIdx.x & 7);        // (pair, chunk) unit
+    if (unit >= npairs * nchunks) return;
+    const int pair = unit / nchunks, chunk = unit - pair * nchunks;
     const int2 qt = pairs[pair];
     const int nq = lcounts[qt.x], nt = lcounts[qt.y];
-    const int qb = blockIdx.x * (64 * kKnnWaves);       // first query of the workgroup
+    const int qb = (slot - grp * qblocks) * (64 * kKnnWaves);   // first query of the workgroup
     if (qb >= nq) return;
     const int t0 = chunk * kKnnChunk;
     const int tn = min(nt - t0, kKnnChunk);             // trains of this chunk
@@ -1042,24 +1052,21 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint4 *__restrict
         const v4i B9 = {half == 0 ? 0x4001 : 0, 0, 0, 0};
         const uint4 *Et = E + ((size_t)qt.y * tilesPerSet + (t0 >> 5)) * kTileU4;
         const int nstage = (tn + 32 * kKnnStageTiles - 1) / (32 * kKnnStageTiles);
-        constexpr int kPer = kKnnStageTiles * kTileU4 / (64 * kKnnWaves);   // uint4 per thread per stage (4)
-        uint4 pre[kPer];
-        auto fetch = [&](int st) {   // tiles wholly past the end are not fetched (their LDS content is never used)
+        constexpr int kPer = kKnnStageTiles * kTileU4 / (64 * kKnnWaves);   // 1-KiB wave transfers per wave per stage (4)
+        auto fill = [&](int st, int buf) {   // linear copy of the stage, one 1-KiB LDS-DMA per wave and k; tiles wholly past the end are skipped
 #pragma unroll
             for (int k = 0; k < kPer; k++) {
-                const int e = k * (64 * kKnnWaves) + tid;   // element of the stage
-                pre[k] = (st * kKnnStageTiles + e / kTileU4) * 32 < tn ? Et[(size_t)st * kKnnStageTiles * kTileU4 + e] : uint4{0, 0, 0, 0};
+                const int e0 = k * (64 * kKnnWaves) + wave * 64;            // first element of this wave's transfer
+                if ((st * kKnnStageTiles + e0 / kTileU4) * 32 < tn)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Et + (size_t)st * kKnnStageTiles * kTileU4 + e0 + lane),
+                                                     (__attribute__((address_space(3))) void *)(&stage[buf][e0]), 16, 0, 0);
             }
         };
-        auto commit = [&](int buf) {
-#pragma unroll
-            for (int k = 0; k < kPer; k++) stage[buf][k * (64 * kKnnWaves) + tid] = pre[k];
-        };
-        fetch(0);
-        commit(0);
+        fill(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (int st = 0; st < nstage; st++) {
-            if (st + 1 < nstage) fetch(st + 1);   // travels while this stage is multiplied
+            if (st + 1 < nstage) fill(st + 1, (st + 1) & 1);   // travels while this stage is multiplied (that buffer was last read a barrier ago)
             const uint4 *S = stage[st & 1];
 #pragma unroll
             for (int tl = 0; tl < kKnnStageTiles; tl++) {
@@ -1097,7 +1104,7 @@ __global__ __launch_bounds__(64 * kKnnWaves) void k_knn2(const uint4 *__restrict
                         k0[u] = max(k0[u], x);
                     }
             }
-            if (st + 1 < nstage) commit((st + 1) & 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next stage has landed
             __syncthreads();
         }
     }
@@ -1299,28 +1306,55 @@ void launch_pyramid(hipStream_t st, uint8_t *pyr, const Geom &g, const ResizeTap
     }
 }
 
-void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, uint32_t *cell_kp,
-                 int *cell_cnt, int nimg)
+void fast_layout(const Geom &g, int &tp, int &rows)
 {
-    // LDS per wave: ROI rows x pitch (3 phase bytes + wCell + 6, rounded up to whole 16-byte chunks) for the tile, four
-    // rows fewer for the score map, the bounded survivor list
-    int pitch = 0, rows = 0;
+    // LDS tile of a cell: ROI rows x pitch (3 phase bytes + wCell + 6, rounded up to whole 16-byte chunks)
+    int pitch = 0;
+    rows = 0;
     for (int l = 0; l < g.nlevels; l++) {
         const int p = ((3 + g.lv[l].wCell + 6 + 15) >> 4) << 4;
         pitch = pitch > p ? pitch : p;
         rows = rows > g.lv[l].hCell + 6 ? rows : g.lv[l].hCell + 6;
     }
-    const int tp = pitch <= 48 ? 48 : (pitch <= 64 ? 64 : 80);   // wCell < 70 by construction (build_geometry): pitch <= 80
-    const int tileB = (rows * tp + 15) & ~15, scB = ((rows - 4) * tp + 15) & ~15;
+    tp = pitch <= 48 ? 48 : (pitch <= 64 ? 64 : 80);   // wCell < 70 by construction (build_geometry): pitch <= 80
+}
+
+int fast_item_table(const Geom &g, std::vector<uint32_t> &tab)
+{
+    int tp, rows;
+    fast_layout(g, tp, rows);
+    const int hiMax = rows - 6, stride = hiMax * kFastMaxGroups + 64;
+    tab.assign((size_t)(kFastMaxGroups + 1) * 2 * stride, 0u);
+    for (int ng = 1; ng <= kFastMaxGroups; ng++)
+        for (int g0 = 0; g0 < 2; g0++) {
+            uint32_t *t = tab.data() + (size_t)(ng * 2 + g0) * stride;
+            for (int i = 0; i < stride; i++) {
+                int r = i / ng;
+                const int gi = i - r * ng;
+                if (r > hiMax - 1) r = hiMax - 1;   // padding past the last item: any in-range address
+                const int G = g0 + gi < tp / 4 ? g0 + gi : tp / 4 - 1;
+                t[i] = (uint32_t)((r + 3) * tp + 4 * G) | ((uint32_t)G << 16);
+            }
+        }
+    return stride;
+}
+
+void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, const uint32_t *tab, int tabStride,
+                 uint32_t *cell_kp, int *cell_cnt, int nimg)
+{
+    // LDS per wave: the tile, the score map (four rows fewer), the column masks, the bounded survivor list
+    int tp, rows;
+    fast_layout(g, tp, rows);
     static const int cap_env = getenv("MCORB_FAST_LISTCAP") ? atoi(getenv("MCORB_FAST_LISTCAP")) : 0;   // tuning knob; any value >= 512 is safe
     const int cap = cap_env >= 512 ? cap_env : kFastListCap;
+    const int tileB = (rows * tp + 15) & ~15, scB = ((rows - 4) * tp + 15) & ~15;
     const size_t lds = 16 + (size_t)tileB + 16 + (size_t)scB + 16 + (size_t)(tp / 4 + 1) * 8 + (size_t)cap * 2;
     dim3 grid(g.cells, nimg);
     if (iniTh < 0) iniTh = 0;   // (the kernel's column masks rely on thresholds >= 0; FAST thresholds are)
     if (minTh < 0) minTh = 0;
-    if (tp == 48) hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, cell_kp, cell_cnt);
-    else if (tp == 64) hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, cell_kp, cell_cnt);
-    else hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, cell_kp, cell_cnt);
+    if (tp == 48) hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, tab, tabStride, cell_kp, cell_cnt);
+    else if (tp == 64) hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, tab, tabStride, cell_kp, cell_cnt);
+    else hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, tab, tabStride, cell_kp, cell_cnt);
 }
 
 void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt, const Geom &g, const uint16_t *lut,
@@ -1374,11 +1408,11 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
     hipLaunchKernelGGL(k_expand, dim3((kcap + 255) / 256, nsets), dim3(256), 0, st, desc, counts, setmap, kcap, E, lcounts);
     if (ev_exp) (void)hipEventRecord(ev_exp, st);
     const int nchunks = (kcap + kKnnChunk - 1) / kKnnChunk;
-    dim3 grid((kcap + 64 * kKnnWaves - 1) / (64 * kKnnWaves), nchunks, npairs);
-    static const int stage_env = getenv("MCORB_KNN_STAGE") ? atoi(getenv("MCORB_KNN_STAGE")) : 0;
-    if (stage_env == 1) hipLaunchKernelGGL(k_knn2<1>, grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, part);
-    else if (stage_env == 4) hipLaunchKernelGGL(k_knn2<4>, grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, part);
-    else hipLaunchKernelGGL(k_knn2<2>, grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, part);
+    const int qblocks = (kcap + 64 * kKnnWaves - 1) / (64 * kKnnWaves), units = npairs * nchunks;
+    dim3 grid(8 * qblocks * ((units + 7) / 8));
+    // 130 VGPRs: 3 waves per SIMD.  (Capping at 128 for 4 waves spills one query fragment into scratch: 177 vs 162 us.)
+    hipLaunchKernelGGL((k_knn2<2, 3>), grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, npairs, qblocks, part);
+
     if (ev_mid) (void)hipEventRecord(ev_mid, st);
     hipLaunchKernelGGL(k_knn2_finalize, dim3(npairs), dim3(1024), 0, st, part, lcounts, pairs, kcap, nchunks, dist_thresh, ratio, out, mlist,
                        mcount);
