@@ -648,20 +648,6 @@ __global__ __launch_bounds__(kCompactWG) void k_compact(const uint32_t *__restri
 // packed u16 (every partial sum <= 65280, so v_pk_* arithmetic is exact), vertical
 // pass in 32 bits, dword stores.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t load4_reflect(const uint8_t *plane, int pitch, int w, int sy, int x)
-{
-    const uint8_t *row = plane + (size_t)sy * pitch;
-    if (x >= 0 && x + 3 < w) return *reinterpret_cast<const uint32_t *>(row + x);   // x is a multiple of 4
-    uint32_t v = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int sx = reflect101(x + k, w);
-        sx = sx < 0 ? 0 : (sx >= w ? w - 1 : sx);   // tiles over-cover the right edge; those bytes are never used
-        v |= (uint32_t)row[sx] << (8 * k);
-    }
-    return v;
-}
-
 __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, uint8_t *__restrict__ blur, Geom g)
 {
     constexpr int TW = kBlurTW, TH = kBlurTH;
@@ -710,11 +696,46 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
         }
         if (tid < 2 * (TH + 6)) in32[ar * ID + A0 + (aside ? TW / 4 + 1 : 0)] = ap;
     } else {
-        for (int i = tid; i < (TH + 6) * (TW / 4 + 2); i += 256) {
-            const int r = i / (TW / 4 + 2), d = i - r * (TW / 4 + 2);
+        // edge tile: the same 16-byte fills with REFLECT_101 row indices; columns outside the image come in as whatever
+        // lies there (row padding, the neighbouring row -- always inside the image block, which ends with 256 spare bytes)
+        // and are then overwritten, per row, with the reflected pixels: only tile columns -4..-1 (left edge) and
+        // w .. w+2 (right edge) can ever be read by an output inside the image.
+        constexpr int QR = TW / 16;
+        constexpr int NQ = ((TH + 6) * QR + 255) / 256;
+        auto src_row = [&](int r) {
             int sy = reflect101(y0 + r - 3, L.h);
-            sy = sy < 0 ? 0 : (sy >= L.h ? L.h - 1 : sy);
-            in32[r * ID + A0 + d] = load4_reflect(plane, L.pitch, L.w, sy, x0 - 4 + 4 * d);
+            sy = sy < 0 ? 0 : (sy >= L.h ? L.h - 1 : sy);   // rows far below the image (tiles over-cover): never used
+            return plane + (size_t)sy * L.pitch + x0;
+        };
+        uint4 v[NQ];
+#pragma unroll
+        for (int k = 0; k < NQ; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / QR, q = i - r * QR;
+            v[k] = i < (TH + 6) * QR ? *reinterpret_cast<const uint4 *>(src_row(r) + 16 * q) : uint4{0, 0, 0, 0};
+        }
+        uint32_t ap = 0;
+        const int ar = tid >> 1, aside = tid & 1;
+        if (tid < 2 * (TH + 6) && (aside || x0 > 0)) ap = *reinterpret_cast<const uint32_t *>(src_row(ar) + (aside ? TW : -4));
+#pragma unroll
+        for (int k = 0; k < NQ; k++) {
+            const int i = tid + 256 * k;
+            const int r = i / QR, q = i - r * QR;
+            if (i < (TH + 6) * QR) *reinterpret_cast<uint4 *>(in32 + r * ID + A0 + 1 + 4 * q) = v[k];
+        }
+        if (tid < 2 * (TH + 6)) in32[ar * ID + A0 + (aside ? TW / 4 + 1 : 0)] = ap;
+        const int e = L.w - 1 - x0;   // tile column of the image's last pixel
+        if (x0 == 0 || e <= TW + 2) {
+            __syncthreads();
+            if (tid < TH + 6) {
+                uint8_t *row = reinterpret_cast<uint8_t *>(in32 + tid * ID + A0 + 1);   // row[c] = tile column c, c in [-4, TW + 4)
+                if (x0 == 0) { row[-1] = row[1]; row[-2] = row[2]; row[-3] = row[3]; row[-4] = row[4]; }
+                if (e <= TW + 2) {
+#pragma unroll
+                    for (int k = 1; k <= 3; k++)
+                        if (e + k <= TW + 3) row[e + k] = row[e - k];
+                }
+            }
         }
     }
     __syncthreads();
