@@ -10,7 +10,7 @@ constexpr int kEdge = 19;          // EDGE_THRESHOLD, ORBextractor.cpp:72
 constexpr int kMinBorder = 16;     // EDGE_THRESHOLD-3, ORBextractor.cpp:788
 constexpr int kCellW = 35;         // W, ORBextractor.cpp:784
 constexpr int kMaxRoi = 76;        // wCell < 70 by construction, +6 overlap
-constexpr int kResizeTileH = 16;              // output rows per resize workgroup (kResizeRows in the kernel)
+constexpr int kResizeTileH = 32;              // output rows per resize workgroup (kResizeRows in the kernel)
 constexpr int kBlurTW = 128, kBlurTH = 32;   // blur output tile per workgroup
 constexpr int kTilePitch = 80;     // LDS pitch of a FAST cell tile (3 phase bytes + 76, multiple of 4)
 

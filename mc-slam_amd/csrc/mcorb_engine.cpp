@@ -117,7 +117,9 @@ void build_resize_axis(int ssize, int dsize, bool is_x, std::vector<ResizeTap> &
         t.s0 = (uint16_t)s0; t.s1 = (uint16_t)s1; t.c0 = (int16_t)c0; t.c1 = (int16_t)c1;
         out.push_back(t);
     }
-    while ((out.size() - first) % pad_to) out.push_back(ResizeTap{0, 0, 0, 0});
+    // padding: copies of the last tap, so that a kernel reading whole groups of `pad_to` never sees an out-of-range column
+    const ResizeTap last = out.size() > first ? out.back() : ResizeTap{0, 0, 0, 0};
+    while ((out.size() - first) % pad_to) out.push_back(last);
 }
 
 int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g, std::vector<ResizeTap> &taps,

@@ -114,26 +114,31 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
     const uint4 t01 = *reinterpret_cast<const uint4 *>(tabs + D.xtab + dx4);       // 4 taps, 8 bytes each
     const uint4 t23 = *reinterpret_cast<const uint4 *>(tabs + D.xtab + dx4 + 2);
     const uint32_t tw[8] = {t01.x, t01.y, t01.z, t01.w, t23.x, t23.y, t23.z, t23.w};
+    // The table is padded to a multiple of four with copies of the row's last tap (build_resize_axis), so the taps of
+    // columns past the image's edge are in range like any other; their pixels are masked out of the store.
+    // (Reading the second sample at s0 + 1 through the same address register lets the compiler merge the two byte reads
+    // into one ds_read_u16 at an odd address; unaligned LDS reads are slow on gfx950: 663 vs 239 us for the seven launches.)
     int s0[4], s1[4], a0[4], a1[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const bool ok = dx4 + k < D.w;   // padded taps point at column 0 of the image, which may be outside the window
-        s0[k] = ok ? (int)(tw[2 * k] & 0xffff) - sx0 : 0;
-        s1[k] = ok ? (int)(tw[2 * k] >> 16) - sx0 : 0;
-        a0[k] = ok ? (int)(short)(tw[2 * k + 1] & 0xffff) : 0;
-        a1[k] = ok ? (int)(short)(tw[2 * k + 1] >> 16) : 0;
+        s0[k] = (int)(tw[2 * k] & 0xffff) - sx0;
+        s1[k] = (int)(tw[2 * k] >> 16) - sx0;
+        a0[k] = (int)(short)(tw[2 * k + 1] & 0xffff);
+        a1[k] = (int)(short)(tw[2 * k + 1] >> 16);
     }
     const uint32_t mask = dx4 + 4 > D.w ? 0xffffffffu >> (8 * (dx4 + 4 - D.w)) : 0xffffffffu;   // keep the row padding zero
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the row taps become scalar loads
-    // Each wave produces 4 CONSECUTIVE output rows.  Consecutive rows share source rows (s1 of row j is s0 of row j+1
-    // five times out of six at scale 1.2), so the horizontal two-tap sums R = S[s0]*a0 + S[s1]*a1 are kept per source
+    // Each wave produces kResizeRows / 4 CONSECUTIVE output rows.  Consecutive rows share source rows (s1 of row j is s0 of
+    // row j+1 five times out of six at scale 1.2), so the horizontal two-tap sums R = S[s0]*a0 + S[s1]*a1 are kept per source
     // row in two register sets and computed once (the row indices are wave-uniform: the reuse tests are scalar branches).
+    // All products fit 24 bits (coefficients <= 2048, samples <= 255, sums >> 4 <= 32640): v_mul/mad_u32_u24 are exact and
+    // full rate (v_mul_lo_u32 is a quarter of that).
     int rowA = -1, rowB = -1;
-    int HA[4], HB[4];
-    auto hrow = [&](int sr, int *Hout) {
+    uint32_t HA[4], HB[4];
+    auto hrow = [&](int sr, uint32_t *Hout) {
         const uint8_t *S = win + (sr - sy0) * srcPitch;
 #pragma unroll
-        for (int k = 0; k < 4; k++) Hout[k] = (S[s0[k]] * a0[k] + S[s1[k]] * a1[k]) >> 4;
+        for (int k = 0; k < 4; k++) Hout[k] = (__umul24((uint32_t)S[s0[k]], (uint32_t)a0[k]) + __umul24((uint32_t)S[s1[k]], (uint32_t)a1[k])) >> 4;
     };
 #pragma unroll
     for (int rr = 0; rr < kResizeRows / 4; rr++) {
@@ -160,14 +165,16 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
             }
             rowB = r1;
         }
-        const int *H0 = HA, *H1 = HB;
-        const int b0 = ty.c0, b1 = ty.c1;
-        uint32_t out = 0;
+        const uint32_t b0 = (uint32_t)ty.c0, b1 = (uint32_t)ty.c1;
+        // cv: (((b0 * H0) >> 16) + ((b1 * H1) >> 16) + 2) >> 2.  The +2 rides in the first product's upper half
+        // (no carry can reach it from below), the two >> 16 are the upper halves of the products.
+        uint32_t v[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int v = (((b0 * H0[k]) >> 16) + ((b1 * H1[k]) >> 16) + 2) >> 2;
-            out |= (uint32_t)(v & 0xff) << (8 * k);
+            const uint32_t p0 = __umul24(b0, HA[k]) + 0x20000u, p1 = __umul24(b1, HB[k]);
+            v[k] = ((p0 >> 16) + (p1 >> 16)) >> 2;   // <= 255
         }
+        const uint32_t out = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
         *reinterpret_cast<uint32_t *>(base + D.off + (size_t)dy * D.pitch + dx4) = out & mask;
     }
 }
