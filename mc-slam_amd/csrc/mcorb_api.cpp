@@ -308,8 +308,19 @@ static int copy_plane(mcorb_rig *r, int slot, int m, int level, bool blurred, ui
     }
     HIPCHK(hipSetDevice(r->rig.device));
     HIPCHK(hipStreamSynchronize(s->st));
-    const uint8_t *src = (blurred ? s->d_blur : s->d_pyr) + (size_t)m * g.imgBytes + g.lv[level].off;
-    HIPCHK(hipMemcpy2D(dst, dst_stride, src, g.lv[level].pitch, g.lv[level].w, g.lv[level].h, hipMemcpyDeviceToHost));
+    const LevelGeom &L = g.lv[level];
+    const uint8_t *src = (blurred ? s->d_blur : s->d_pyr) + (size_t)m * g.imgBytes + L.off;
+    if (!blurred) {
+        HIPCHK(hipMemcpy2D(dst, dst_stride, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
+        return MCORB_OK;
+    }
+    // blurred planes live in 16 x 8 tiles on the device (mcorb_common.h): fetch the tiled block, hand back rows
+    const size_t rows = ((size_t)L.h + kBlurTileRows - 1) / kBlurTileRows * kBlurTileRows;
+    std::vector<uint8_t> tmp(rows * L.pitch);
+    HIPCHK(hipMemcpy(tmp.data(), src, tmp.size(), hipMemcpyDeviceToHost));
+    for (int y = 0; y < L.h; y++)
+        for (int x = 0; x < L.w; x += kBlurTileCols)
+            memcpy(dst + (size_t)y * dst_stride + x, tmp.data() + blur_tiled_offset(L.pitch, x, y), (size_t)std::min(kBlurTileCols, L.w - x));
     return MCORB_OK;
 }
 int mcorb_rig_get_level(mcorb_rig *r, int slot, int m, int level, uint8_t *dst, int dst_stride)

@@ -41,6 +41,19 @@ struct BowRes { int32_t word, nodeup; double weight; };
 // Packed selected keypoint handed back to the device: level (4) | y (14) | x (14), level coordinates.
 __host__ __device__ inline uint32_t pack_sel(int level, int x, int y) { return ((uint32_t)level << 28) | ((uint32_t)y << 14) | (uint32_t)x; }
 
+// The BLURRED planes are stored in tiles of 16 px x 8 rows = 128 bytes (one fabric line): k_describe stages a
+// 27 x 27 neighbourhood per keypoint, which is 27 lines of a row-major plane but 12-15 tiles.  Tile (tr, tc) of a
+// level sits at (tr * pitch / 16 + tc) * 128, pixel (x, y) at byte (y & 7) * 16 + (x & 15) of its tile.  Only k_blur
+// writes this layout and only k_describe* / mcorb_rig_get_blurred read it; the un-blurred pyramid stays row-major.
+constexpr int kBlurTileRows = 8, kBlurTileCols = 16, kBlurTileBytes = 128;
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline size_t blur_tiled_offset(int pitch, int x, int y)
+{
+    return ((size_t)(y >> 3) * (size_t)(pitch >> 4) + (size_t)(x >> 4)) * kBlurTileBytes + (size_t)((y & 7) << 4) + (size_t)(x & 15);
+}
+
 struct LevelGeom {
     int w, h;            // level size (ORBextractor.cpp:1177-1178)
     int pitch;           // bytes per row in HBM (multiple of 64)

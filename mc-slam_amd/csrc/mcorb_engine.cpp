@@ -172,7 +172,7 @@ int build_geometry(const mcorb_params &p, const Tables &t, int W, int H, Geom &g
         if (L.w > 4096 || L.h > 4096) { set_error("image larger than 4096 px"); return MCORB_E_SIZE; }
         L.pitch = (int)align_up((size_t)L.w, 64);
         L.off = (uint32_t)off;
-        off += align_up((size_t)L.pitch * L.h, 256);
+        off += align_up((size_t)L.pitch * align_up((size_t)L.h, kBlurTileRows), 256);   // whole 16x8 tiles (blurred planes)
         L.cell0 = cells;
         cells += L.nCols * L.nRows;
         L.tilesX = (L.w + kBlurTW - 1) / kBlurTW;

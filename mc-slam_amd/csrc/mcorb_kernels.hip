@@ -782,8 +782,9 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
     }
 #define KK(lo, hi) (u16x2{(unsigned short)(lo), (unsigned short)(hi)})
 #define DOT(a, k, c) __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), k, c, false)
-    uint8_t *oplane = blur + (size_t)img * g.imgBytes + L.off;
-    const int x = x0 + 4 * gx;
+    // The output goes through LDS (in32 is dead since the horizontal pass) so that it reaches HBM as whole tiles of the
+    // 16 x 8 blurred-plane layout (mcorb_common.h): eight lanes write one 128-byte line.
+    static_assert(ID >= TW / 4 && (TH + 6) * ID >= TH * ID, "output staging reuses the input rows");
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         uint32_t acc[4];
@@ -805,9 +806,15 @@ __global__ __launch_bounds__(256) void k_blur(const uint8_t *__restrict__ pyr, u
             acc[j] = a;
         }
         // (acc + 32768) >> 16 fits a byte: pick byte 2 of each accumulator
-        const uint32_t out = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
-        const int y = y0 + rg * 4 + k;
-        if (x < L.w && y < L.h) *reinterpret_cast<uint32_t *>(oplane + (size_t)y * L.pitch + x) = out;
+        in32[(rg * 4 + k) * ID + gx] = __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
+    }
+    __syncthreads();
+    {
+        static_assert(TW == 128 && TH == 32, "one 16-byte tile row per thread: 4 x 8 tiles of 16 x 8");
+        const int tc = (tid >> 3) & 7, tr = tid >> 6, sr = tid & 7;
+        const int x = x0 + 16 * tc, y = y0 + 8 * tr + sr;
+        const uint4 o = *reinterpret_cast<const uint4 *>(in32 + (8 * tr + sr) * ID + 4 * tc);
+        if (x < L.w && y < L.h) *reinterpret_cast<uint4 *>(blur + (size_t)img * g.imgBytes + L.off + blur_tiled_offset(L.pitch, x, y)) = o;
     }
 #undef KK
 #undef DOT
@@ -850,11 +857,13 @@ __device__ __forceinline__ float fast_atan2_deg(float y, float x)
 }
 
 constexpr int kDescPerWave = 4;   // keypoints per wave
-constexpr int kPatchRows = 27, kPatchDw = 8;   // unrotated taps lie within +-13 px: 27 rows x 32 aligned bytes
+constexpr int kPatchRows = 27, kPatchDw = 12;  // unrotated taps lie within +-13 px: 27 rows x 3 tile columns of 16 bytes
 
-// Reference behaviour (angle = 0): the 27x27 neighbourhood of each keypoint is staged in LDS with
-// row-coalesced dword loads, then the 512 taps are LDS byte reads.  (Gathering the taps straight
-// from global memory is bound by the texture addresser at ~1 lane/clk for divergent byte loads.)
+// Reference behaviour (angle = 0): the 27x27 neighbourhood of each keypoint is staged in LDS, then the 512 taps are
+// LDS byte reads.  (Gathering the taps straight from global memory is bound by the texture addresser at ~1 lane/clk
+// for divergent byte loads.)  The blurred plane is tiled 16 x 8 (mcorb_common.h): the window is the three tile
+// columns from (kx - 13) >> 4 on, 81 aligned 16-byte loads touching 12-15 lines of 128 bytes (27 rows of a row-major
+// plane were 27 lines, which made this kernel move 5.7x its algorithmic bytes).
 __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ blur, Geom g,
                                                   const uint32_t *__restrict__ sel, const int *__restrict__ nsel,
                                                   uint8_t *__restrict__ desc)
@@ -866,23 +875,39 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
     const int n = nsel[img];
     if (k0 >= n) return;
 
+    static_assert(kPatchDw == 12 && kPatchRows * 3 <= 128, "patch staging assumes 48-byte rows, two trips of 64 lanes");
+    // staging task t = 64 * trip + lane = row * 3 + tile column
+    int trow[2], tcol[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int t = 64 * q + lane;
+        trow[q] = t / 3;
+        tcol[q] = t - 3 * trow[q];
+    }
     int shift[kDescPerWave];
+    uint4 v[kDescPerWave][2];
 #pragma unroll
     for (int u = 0; u < kDescPerWave; u++) {
         const int k = k0 + u < n ? k0 + u : n - 1;   // tail keypoints are recomputed, never stored
         const uint32_t s = sel[(size_t)img * g.kcap + k];
         const int level = (int)(s >> 28), ky = (int)((s >> 14) & 0x3fffu), kx = (int)(s & 0x3fffu);
         const LevelGeom &L = g.lv[level];
-        const int bx = (kx - 13) & ~3;               // keypoints sit >= 19 px from every edge: window is in range
-        shift[u] = kx - bx;                           // 13..16
-        const uint8_t *src = blur + (size_t)img * g.imgBytes + L.off + (size_t)(ky - 13) * L.pitch + bx;
-        // 27 rows x 32 bytes: one 16-byte load per lane (54 lanes), 4-byte aligned in HBM, 16-byte aligned in LDS
-        static_assert(kPatchDw == 8 && kPatchRows * 2 <= 64, "patch staging assumes 32-byte rows, two lanes per row");
-        struct __attribute__((packed, aligned(4))) Chunk { uint32_t a, b, c, d; };
-        if (lane < kPatchRows * 2) {
-            const Chunk v = *reinterpret_cast<const Chunk *>(src + (size_t)(lane >> 1) * L.pitch + 16 * (lane & 1));
-            *reinterpret_cast<uint4 *>(&patch[wave][u][lane * 4]) = uint4{v.a, v.b, v.c, v.d};
+        const int tc0 = (kx - 13) >> 4;              // keypoints sit >= 19 px from every edge: tile columns tc0 .. tc0+2 exist
+        shift[u] = kx - 16 * tc0;                     // 13..28
+        const uint8_t *plane = blur + (size_t)img * g.imgBytes + L.off;
+        const int tpr = L.pitch >> 4;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int yy = ky - 13 + trow[q];
+            v[u][q] = (q == 0 || lane < kPatchRows * 3 - 64)
+                          ? *reinterpret_cast<const uint4 *>(plane + ((size_t)((yy >> 3) * tpr + tc0 + tcol[q]) << 7) + ((yy & 7) << 4))
+                          : uint4{0, 0, 0, 0};
         }
+    }
+#pragma unroll
+    for (int u = 0; u < kDescPerWave; u++) {
+        *reinterpret_cast<uint4 *>(&patch[wave][u][lane * 4]) = v[u][0];
+        if (lane < kPatchRows * 3 - 64) *reinterpret_cast<uint4 *>(&patch[wave][u][(64 + lane) * 4]) = v[u][1];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -952,7 +977,7 @@ __global__ __launch_bounds__(256) void k_describe_oriented(const uint8_t *__rest
     const float rad = __fmul_rn(ang, (float)(3.14159265358979323846 / 180.f));
     const float ca = cosf(rad), sa = sinf(rad);
 
-    const uint8_t *cb = blur + coff;
+    const uint8_t *cb = blur + (size_t)img * g.imgBytes + L.off;   // tiled 16 x 8 (mcorb_common.h)
     unsigned long long bits[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -963,7 +988,7 @@ __global__ __launch_bounds__(256) void k_describe_oriented(const uint8_t *__rest
         const int ox0 = __float2int_rn(__fsub_rn(__fmul_rn(x0, ca), __fmul_rn(y0, sa)));
         const int oy1 = __float2int_rn(__fadd_rn(__fmul_rn(x1, sa), __fmul_rn(y1, ca)));
         const int ox1 = __float2int_rn(__fsub_rn(__fmul_rn(x1, ca), __fmul_rn(y1, sa)));
-        const int t0 = cb[oy0 * pitch + ox0], t1 = cb[oy1 * pitch + ox1];
+        const int t0 = cb[blur_tiled_offset(pitch, kx + ox0, ky + oy0)], t1 = cb[blur_tiled_offset(pitch, kx + ox1, ky + oy1)];
         bits[j] = __ballot(t0 < t1);
     }
     if (lane < 4) {
