@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <sched.h>
 #include <algorithm>
 #include <new>
 #include <cmath>
@@ -323,6 +324,30 @@ void WorkerPool::parallel_for(int n, const std::function<void(int, int)> &fn, in
 // ---------------------------------------------------------------------------
 // Rig
 // ---------------------------------------------------------------------------
+// Cores this process can actually use: hardware threads, cut down to the scheduler affinity mask and to the cgroup CPU
+// quota (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us), whichever is smallest.
+static int usable_cores()
+{
+    int n = (int)std::thread::hardware_concurrency();
+    if (n < 1) n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, std::max(1, CPU_COUNT(&set)));
+    long long quota = -1, period = 0;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[32] = {0};
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atoll(q);
+        fclose(f);
+    } else {
+        FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"), *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+        if (fq && fp && fscanf(fq, "%lld", &quota) == 1 && fscanf(fp, "%lld", &period) == 1) {}
+        else quota = -1;
+        if (fq) fclose(fq);
+        if (fp) fclose(fp);
+    }
+    if (quota > 0 && period > 0) n = std::min(n, (int)std::max(1LL, quota / period));
+    return n;
+}
+
 template <typename T>
 static int dev_alloc(T **p, size_t n)
 {
@@ -402,12 +427,18 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     }
     HIPCHK(upload_umax(tab.umax));
 
-    int nthreads = p.host_threads > 0 ? p.host_threads : (int)std::thread::hardware_concurrency();
+    // Host threads: the selection workers, one driver per slot (spinning on its events unless the rig sleeps, below) and
+    // the submitting thread all draw on the cores this process may use -- the scheduler affinity AND the cgroup CPU quota
+    // (a GPU box gives 16 cores per GPU: with 16 workers + 6 spinning drivers the quota ran out in 10 of 40 periods and the
+    // whole process was stalled for 5-15 ms each time, 15 % of the throughput).  Default: what is left after the drivers
+    // and the caller, at most one worker per image of a batch and at most 16.
+    const int cores = usable_cores();
+    int nthreads = p.host_threads > 0 ? p.host_threads : cores - nslots - 2;
+    bool crowded = false;   // too few cores for spinning drivers: they sleep on their events instead
+    if (p.host_threads <= 0 && nthreads < 4) { crowded = true; nthreads = cores - 2; }
+    if (p.host_threads <= 0) nthreads = std::max(2, std::min(nthreads, std::min(max_images, 16)));
     if (getenv("MCORB_HOST_THREADS")) nthreads = atoi(getenv("MCORB_HOST_THREADS"));
-    if (nthreads < 1) nthreads = 1;
-    // default: one worker per image of a batch, at most 16 (the CPU share that goes with one GPU)
-    if (p.host_threads <= 0) nthreads = std::min(nthreads, std::max(2, std::min(max_images, 16)));
-    nthreads = std::min(nthreads, 64);
+    nthreads = std::max(1, std::min(nthreads, 64));
     pool = new WorkerPool(nthreads);
     pool_threads = nthreads;
     for (int i = 0; i < nthreads + nslots; i++) scratch.push_back(new SelectScratch);   // workers, then one per slot's submitting thread
@@ -429,7 +460,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         // measured 2-4 % faster than interrupt-driven waits at 6 slots; with many slots the spinning drivers would take
         // the cores the selection workers need, so those rigs sleep instead.  MCORB_SYNC=block|spin overrides.
         const char *sync_env = getenv("MCORB_SYNC");
-        const bool blocking = sync_env ? !strcmp(sync_env, "block") : nslots > 8;
+        const bool blocking = sync_env ? !strcmp(sync_env, "block") : (nslots > 8 || crowded);
         HIPCHK(hipEventCreateWithFlags(&s->ev_x, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_c, hipEventDefault));
         HIPCHK(hipEventCreateWithFlags(&s->ev_e, hipEventDefault));
