@@ -97,6 +97,16 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
     const int sx0 = tabs[D.xtab + bx0].s0 & ~15, sx1 = tabs[D.xtab + bx1].s1;
     const int sy0 = tabs[D.ytab + by0].s0, sy1 = tabs[D.ytab + by1].s1;
     const int nq = ((sx1 - sx0) >> 4) + 1, nr = sy1 - sy0 + 1;   // nq*16 <= srcPitch, nr <= srcRows by construction
+    // this wave's row taps, one per lane, fetched now so that the latency hides behind the window fill (read back with
+    // v_readlane below: a load inside the row loop is a vector load the whole wave waits for, eight times in a row)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wy0 = by0 + wave * (kResizeRows / 4);
+    uint2 ytap;
+    {
+        const int l = tid & 63;
+        const int dy = min(wy0 + (l < kResizeRows / 4 ? l : 0), D.h - 1);
+        ytap = *reinterpret_cast<const uint2 *>(tabs + D.ytab + dy);
+    }
     {
         const uint8_t *sp = base + S.off + (size_t)sy0 * S.pitch + sx0;
         uint4 *w128 = reinterpret_cast<uint4 *>(win);
@@ -127,7 +137,6 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
         a1[k] = (int)(short)(tw[2 * k + 1] >> 16);
     }
     const uint32_t mask = dx4 + 4 > D.w ? 0xffffffffu >> (8 * (dx4 + 4 - D.w)) : 0xffffffffu;   // keep the row padding zero
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the row taps become scalar loads
     // Each wave produces kResizeRows / 4 CONSECUTIVE output rows.  Consecutive rows share source rows (s1 of row j is s0 of
     // row j+1 five times out of six at scale 1.2), so the horizontal two-tap sums R = S[s0]*a0 + S[s1]*a1 are kept per source
     // row in two register sets and computed once (the row indices are wave-uniform: the reuse tests are scalar branches).
@@ -136,16 +145,16 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
     int rowA = -1, rowB = -1;
     uint32_t HA[4], HB[4];
     auto hrow = [&](int sr, uint32_t *Hout) {
-        const uint8_t *S = win + (sr - sy0) * srcPitch;
+        const uint8_t *S = win + __mul24(sr - sy0, srcPitch);
 #pragma unroll
         for (int k = 0; k < 4; k++) Hout[k] = (__umul24((uint32_t)S[s0[k]], (uint32_t)a0[k]) + __umul24((uint32_t)S[s1[k]], (uint32_t)a1[k])) >> 4;
     };
 #pragma unroll
     for (int rr = 0; rr < kResizeRows / 4; rr++) {
-        const int dy = by0 + wave * (kResizeRows / 4) + rr;
+        const int dy = wy0 + rr;
         if (dy >= D.h) break;
-        const ResizeTap ty = tabs[D.ytab + dy];
-        const int r0 = ty.s0, r1 = ty.s1;
+        const uint32_t ys = (uint32_t)__builtin_amdgcn_readlane((int)ytap.x, rr), yc = (uint32_t)__builtin_amdgcn_readlane((int)ytap.y, rr);
+        const int r0 = (int)(ys & 0xffff), r1 = (int)(ys >> 16);
         // invariant after this block: HA holds source row r0, HB holds source row r1 (register moves, no selects)
         if (r0 != rowA) {
             if (r0 == rowB) {
@@ -165,7 +174,7 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
             }
             rowB = r1;
         }
-        const uint32_t b0 = (uint32_t)ty.c0, b1 = (uint32_t)ty.c1;
+        const uint32_t b0 = yc & 0xffff, b1 = yc >> 16;   // row coefficients: 0 .. 2048
         // cv: (((b0 * H0) >> 16) + ((b1 * H1) >> 16) + 2) >> 2.  The +2 rides in the first product's upper half
         // (no carry can reach it from below), the two >> 16 are the upper halves of the products.
         uint32_t v[4];
