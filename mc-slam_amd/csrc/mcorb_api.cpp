@@ -314,6 +314,12 @@ static int copy_plane(mcorb_rig *r, int slot, int m, int level, bool blurred, ui
         HIPCHK(hipMemcpy2D(dst, dst_stride, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
         return MCORB_OK;
     }
+    if (!s->blur_valid) {   // reference mode never writes blurred planes (k_describe_fused): make them now from the slot's pyramid
+        launch_blur(s->st, s->d_pyr, s->d_blur, g, r->rig.max_images);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(s->st));
+        s->blur_valid = true;
+    }
     // blurred planes live in 16 x 8 tiles on the device (mcorb_common.h): fetch the tiled block, hand back rows
     const size_t rows = ((size_t)L.h + kBlurTileRows - 1) / kBlurTileRows * kBlurTileRows;
     std::vector<uint8_t> tmp(rows * L.pitch);

@@ -439,6 +439,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     if (p.host_threads <= 0) nthreads = std::max(2, std::min(nthreads, std::min(max_images, 16)));
     if (getenv("MCORB_HOST_THREADS")) nthreads = atoi(getenv("MCORB_HOST_THREADS"));
     nthreads = std::max(1, std::min(nthreads, 64));
+    blur_planes = p.orientation != 0 || getenv("MCORB_BLUR_PLANES") != nullptr;
     pool = new WorkerPool(nthreads);
     pool_threads = nthreads;
     for (int i = 0; i < nthreads + nslots; i++) scratch.push_back(new SelectScratch);   // workers, then one per slot's submitting thread
@@ -764,7 +765,11 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
     if (!side) HIPCHK(hipStreamWaitEvent(s.st_copy, s.ev_c, 0));
     HIPCHK(hipMemcpyAsync(s.h_tbl, s.d_tbl, (size_t)j.nimg * s.tbl_ints_per_image * sizeof(int), hipMemcpyDeviceToHost, s.st_copy));
     HIPCHK(hipEventRecord(s.ev[3], s.st_copy));
-    launch_blur(s.st, s.d_pyr, s.d_blur, geom, j.nimg);
+    // Reference mode blurs inside the descriptor kernel, only around the kept keypoints (k_describe_fused).  Whole
+    // blurred planes are made when the rotated taps of the orientation mode need them, when MCORB_BLUR_PLANES asks for
+    // the plane-based path (A/B comparison), or later, on demand, for mcorb_rig_get_blurred.
+    s.blur_valid = blur_planes;
+    if (blur_planes) launch_blur(s.st, s.d_pyr, s.d_blur, geom, j.nimg);
     HIPCHK(hipEventRecord(s.ev[4], s.st));
     HIPCHK(hipGetLastError());
     return MCORB_OK;
@@ -866,7 +871,7 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     // one H2D copy of the control block: counts, pair list, packed selected keypoints
     HIPCHK(hipMemcpyAsync(s.d_ctrl, s.h_ctrl, s.ctrl_bytes, hipMemcpyHostToDevice, s.st));
     HIPCHK(hipEventRecord(s.ev[5], s.st));
-    launch_describe(s.st, s.d_pyr, s.d_blur, geom, s.d_sel, s.d_nsel, params.orientation, s.d_desc, s.d_angles, nimg);
+    launch_describe(s.st, s.d_pyr, blur_planes ? s.d_blur : nullptr, geom, s.d_sel, s.d_nsel, params.orientation, s.d_desc, s.d_angles, nimg);
     HIPCHK(hipEventRecord(s.ev[6], s.st));
     // descriptors go back to the host on the side stream (DMA) while the matcher already runs
     static const bool d2h_late = getenv("MCORB_D2H_LATE") != nullptr;   // experiment: copy after the k-NN instead of beside it

@@ -104,6 +104,7 @@ struct Slot {
     Rig *rig = nullptr;
     int index = 0;
     bool shared_st = false;
+    bool blur_valid = false;   // d_blur holds the blurred planes of the images in d_pyr
     hipStream_t st = nullptr, st_copy = nullptr, st_dma = nullptr;   // compute; PCIe-bound compaction kernel; D2H copies only
     hipEvent_t ev_x = nullptr;   // cross-stream hand-offs with the caller's streams (export / external match)
     hipEvent_t ev_c = nullptr;   // k_compact finished (the table DMA follows it on the side stream)
@@ -209,6 +210,7 @@ public:
     void merge_tracks(Slot &s, int f, const EpipolarGate *gate, std::vector<int32_t> &tr, int &mergeable_out) const;
 
 private:
+    bool blur_planes = false;  // k_blur runs with every job (orientation mode / MCORB_BLUR_PLANES); otherwise blur is fused into k_describe_fused
     void driver(Slot *s);
     int execute(Slot &s, const Job &j);
     int run_extract_phaseA(Slot &s, const Job &j);

@@ -943,6 +943,191 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
     }
 }
 
+// ---------------------------------------------------------------------------
+// Blur + BRIEF in one kernel (reference mode, angle = 0).  The reference blurs every level in full
+// (ORBextractor.cpp:1132-1133) and then reads 512 taps within +-13 px of each kept keypoint (:105-145); the blurred
+// value of a pixel depends on nothing but its own 7 x 7 neighbourhood, so blurring only the 27 x 27 window around each
+// of the ~1000 keypoints per image gives the same bytes while touching a quarter of the pixels -- and the blurred
+// planes never travel to HBM and back (k_blur + k_describe moved 2 x pyramid + 0.35 GB per 128 images and were bound
+// by vector instructions at 17 per blurred pixel).  Keypoints sit >= 19 px from every edge (EDGE_THRESHOLD), so the
+// 33 x 33 source window is always inside the image and BORDER_REFLECT_101 never comes into play.
+//
+// One wave per keypoint at a time (kDescPerWave in sequence, the next window's loads in flight while this one is
+// computed); everything is wave-synchronous, no s_barrier.  Per keypoint, in the wave's own LDS:
+//   src   34 rows x 48 bytes: image rows ky-16 .. ky+16 from the 16-byte aligned column at or below kx-16
+//   hp    horizontal 8.8 sums, two rows per dword (v_dot2 operands), 17 row pairs x 28 columns (kx-13 .. kx+14)
+//   out   blurred window, 28 rows x 32 bytes, row y = image row ky-13+y, column o = image column kx-13+o
+// The fixed-point arithmetic is k_blur's: v_dot4_u32_u8 on byte windows, v_dot2_u32_u16 down the rows, + 32768 >> 16.
+// ---------------------------------------------------------------------------
+constexpr int kFdSrcDw = 34 * 12 + 4;    // + one chunk of slack: the (unused) 28th column of the last row reads past it
+constexpr int kFdPairs = 17, kFdHpPitch = 28, kFdHpDw = kFdPairs * kFdHpPitch;
+constexpr int kFdOutPitchDw = 8, kFdOutDw = 28 * kFdOutPitchDw;
+constexpr int kFdWaveDw = kFdSrcDw + kFdHpDw + kFdOutDw;
+
+template <int B>
+__device__ __forceinline__ uint32_t fd_window(const uint32_t (&D)[4])
+{
+    constexpr int q = B >> 2, sh = B & 3;
+    if constexpr (sh == 0) return D[q];
+    else return __builtin_amdgcn_alignbyte(D[q + 1], D[q], sh);
+}
+
+// horizontal pass for a window whose first source byte sits SH bytes into dword `a` of every row
+template <int SH>
+__device__ __forceinline__ void fd_hpass(const uint32_t *__restrict__ src, uint32_t *__restrict__ hp, int a, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int i = lane + 64 * t;
+        if (i < kFdPairs * 7) {
+            const int p = (int)(__umul24((uint32_t)i, 147u) >> 10), j = i - 7 * p;   // i / 7 for i < 128
+            uint32_t h[2][4];
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const uint32_t *row = src + (2 * p + rr) * 12 + a + j;
+                uint32_t D[4] = {row[0], row[1], row[2], 0u};
+                D[3] = SH == 3 ? row[3] : D[2];   // byte 12 is only ever needed at SH = 3
+                constexpr uint32_t T1 = 0x38302212u, T2 = 0x00122230u;   // taps 18,34,48,56 | 48,34,18,0
+#define FD_HTAP(o) __builtin_amdgcn_udot4(fd_window<SH + (o) + 4>(D), T2, __builtin_amdgcn_udot4(fd_window<SH + (o)>(D), T1, 0u, false), false)
+                h[rr][0] = FD_HTAP(0); h[rr][1] = FD_HTAP(1); h[rr][2] = FD_HTAP(2); h[rr][3] = FD_HTAP(3);
+#undef FD_HTAP
+            }
+            uint4 v;
+            v.x = __builtin_amdgcn_perm(h[1][0], h[0][0], 0x05040100u);
+            v.y = __builtin_amdgcn_perm(h[1][1], h[0][1], 0x05040100u);
+            v.z = __builtin_amdgcn_perm(h[1][2], h[0][2], 0x05040100u);
+            v.w = __builtin_amdgcn_perm(h[1][3], h[0][3], 0x05040100u);
+            *reinterpret_cast<uint4 *>(hp + p * kFdHpPitch + 4 * j) = v;
+        }
+    }
+}
+
+__device__ __forceinline__ void fd_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // a wave only ever reads what it wrote itself
+}
+
+__global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restrict__ pyr, Geom g,
+                                                        const uint32_t *__restrict__ sel, const int *__restrict__ nsel,
+                                                        uint8_t *__restrict__ desc, int groups)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][kFdWaveDw];
+    static_assert(kFdSrcDw % 4 == 0 && kFdHpDw % 4 == 0, "16-byte aligned regions");
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    // 1-D grid, remapped so that each XCD works through whole images one after the other: the windows of neighbouring
+    // keypoints overlap, and with an image's workgroups dealt round-robin over the eight L2s none of that overlap hit
+    // (0.92 GB fetched per 128 images, 7 KB per keypoint).
+    const int b = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x));
+    const int img = b / groups;
+    const int k0 = ((b - img * groups) * 4 + wave) * kDescPerWave;
+    const int n = nsel[img];
+    if (k0 >= n) return;
+    uint32_t *src = lds[wave], *hp = src + kFdSrcDw, *out = hp + kFdHpDw;
+
+    // staging task t = 64 * q + lane = row * 3 + chunk (99 chunks of 16 bytes)
+    int toff[2], tlds[2];
+    bool tact[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int t = 64 * q + lane;
+        tact[q] = t < 99;
+        const int tt = tact[q] ? t : 98;
+        const int row = (int)(__umul24((uint32_t)tt, 171u) >> 9), ch = tt - 3 * row;   // tt / 3 for tt < 128
+        toff[q] = row | (ch << 8);
+        tlds[q] = row * 12 + 4 * ch;
+    }
+    // this lane's four test pairs (pairs lane, 64+lane, 128+lane, 192+lane) as byte offsets into `out`
+    int o0[4], o1[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p = (j * 64 + lane) * 4;
+        o0[j] = (c_pattern[p + 1] + 13) * (kFdOutPitchDw * 4) + c_pattern[p] + 13;
+        o1[j] = (c_pattern[p + 3] + 13) * (kFdOutPitchDw * 4) + c_pattern[p + 2] + 13;
+    }
+
+    // window fetch of keypoint u into (va, vb); kept in plain scalars (an array captured by a lambda ended up in scratch)
+    uint4 va, vb;
+    int kxn;
+#define FD_FETCH(u)                                                                                                         \
+    {                                                                                                                       \
+        const uint32_t s_ = (uint32_t)__builtin_amdgcn_readlane((int)selv, (u));                                            \
+        const int level_ = (int)(s_ >> 28), ky_ = (int)((s_ >> 14) & 0x3fffu), kx_ = (int)(s_ & 0x3fffu);                   \
+        const LevelGeom &L_ = g.lv[level_];                                                                                 \
+        const uint8_t *p0_ = pyr + (size_t)img * g.imgBytes + L_.off + (size_t)(ky_ - 16) * L_.pitch + ((kx_ - 16) & ~15);  \
+        va = *reinterpret_cast<const uint4 *>(p0_ + (size_t)__mul24(toff0 & 0xff, L_.pitch) + 16 * (toff0 >> 8));           \
+        vb = *reinterpret_cast<const uint4 *>(p0_ + (size_t)__mul24(toff1 & 0xff, L_.pitch) + 16 * (toff1 >> 8));           \
+        kxn = kx_;                                                                                                          \
+    }
+    // the wave's keypoint records, one per lane, read back with v_readlane (tail keypoints are recomputed, never stored)
+    const uint32_t selv = sel[(size_t)img * g.kcap + min(k0 + (lane < kDescPerWave ? lane : 0), n - 1)];
+    const int toff0 = toff[0], toff1 = toff[1], tlds0 = tlds[0], tlds1 = tlds[1];
+    const bool tact1 = tact[1];
+    FD_FETCH(0)
+#pragma unroll 1
+    for (int u = 0; u < kDescPerWave; u++) {
+        const int A = (kxn - 16) & 15;   // first source byte of the window inside the staged rows
+        *reinterpret_cast<uint4 *>(src + tlds0) = va;
+        if (tact1) *reinterpret_cast<uint4 *>(src + tlds1) = vb;
+        if (u + 1 < kDescPerWave) FD_FETCH(u + 1)
+        fd_wave_sync();
+        switch (A & 3) {   // wave-uniform: four copies of the pass with compile-time byte shifts
+        case 0: fd_hpass<0>(src, hp, A >> 2, lane); break;
+        case 1: fd_hpass<1>(src, hp, A >> 2, lane); break;
+        case 2: fd_hpass<2>(src, hp, A >> 2, lane); break;
+        default: fd_hpass<3>(src, hp, A >> 2, lane); break;
+        }
+        fd_wave_sync();
+        if (lane < 49) {   // vertical: lane = 4 rows x 4 columns from five row pairs
+            const int rg = (int)(__umul24((uint32_t)lane, 147u) >> 10), j = lane - 7 * rg;
+            uint32_t P[5][4];
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const uint4 w = *reinterpret_cast<const uint4 *>(hp + (2 * rg + q) * kFdHpPitch + 4 * j);
+                P[q][0] = w.x; P[q][1] = w.y; P[q][2] = w.z; P[q][3] = w.w;
+            }
+#define KK(lo, hi) (u16x2{(unsigned short)(lo), (unsigned short)(hi)})
+#define DOT(a, k, c) __builtin_amdgcn_udot2(__builtin_bit_cast(u16x2, a), k, c, false)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                uint32_t acc[4];
+                const int q = k >> 1;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    uint32_t a = 32768u;
+                    if ((k & 1) == 0) {
+                        a = DOT(P[q][c], KK(18, 34), a);
+                        a = DOT(P[q + 1][c], KK(48, 56), a);
+                        a = DOT(P[q + 2][c], KK(48, 34), a);
+                        a = DOT(P[q + 3][c], KK(18, 0), a);
+                    } else {
+                        a = DOT(P[q][c], KK(0, 18), a);
+                        a = DOT(P[q + 1][c], KK(34, 48), a);
+                        a = DOT(P[q + 2][c], KK(56, 48), a);
+                        a = DOT(P[q + 3][c], KK(34, 18), a);
+                    }
+                    acc[c] = a;
+                }
+                out[(4 * rg + k) * kFdOutPitchDw + j] =
+                    __builtin_amdgcn_perm(acc[1], acc[0], 0x0c0c0602u) | __builtin_amdgcn_perm(acc[3], acc[2], 0x06020c0cu);
+            }
+#undef KK
+#undef DOT
+        }
+        fd_wave_sync();
+        const uint8_t *c = reinterpret_cast<const uint8_t *>(out);
+        unsigned long long bits[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) bits[j] = __ballot(c[o0[j]] < c[o1[j]]);
+        if (lane < 4 && k0 + u < n) {
+            const unsigned long long b = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
+            reinterpret_cast<unsigned long long *>(desc + ((size_t)img * g.kcap + k0 + u) * 32)[lane] = b;
+        }
+    }
+#undef FD_FETCH
+}
+
 // IC_Angle enabled (non-reference mode): orientation from the un-blurred level, rotated taps
 // (up to +-19 px) gathered from global memory.
 __global__ __launch_bounds__(256) void k_describe_oriented(const uint8_t *__restrict__ pyr, const uint8_t *__restrict__ blur,
@@ -1458,7 +1643,8 @@ void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, co
         hipLaunchKernelGGL(k_describe_oriented, grid, dim3(256), 0, st, pyr, blur, g, sel, nsel, desc, angles);
     } else {
         dim3 grid((g.kcap + 4 * kDescPerWave - 1) / (4 * kDescPerWave), nimg);
-        hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, blur, g, sel, nsel, desc);
+        if (blur) hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, blur, g, sel, nsel, desc);   // from blurred planes (k_blur ran)
+        else hipLaunchKernelGGL(k_describe_fused, dim3(grid.x * nimg), dim3(256), 0, st, pyr, g, sel, nsel, desc, (int)grid.x);
     }
 }
 
