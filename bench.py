@@ -42,9 +42,9 @@ CONFIGS = {
 }
 IMAGES_PER_LAUNCH = 128     # camera images per slot job (32 four-camera or 16 eight-camera rig frames)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
-GPU_KERNELS = ("k_resize", "k_fast_cells", "k_compact", "k_describe", "k_knn2")   # k_blur: only with MCORB_BLUR_PLANES / orientation
+GPU_KERNELS = ("k_resize", "k_fast_cells", "k_compact", "k_describe_fused", "k_knn2")   # k_blur: only with MCORB_BLUR_PLANES / orientation
 TIMING_FIELD = {"k_resize": "pyramid_us", "k_fast_cells": "fast_us", "k_compact": "compact_us", "k_blur": "blur_us",
-                "k_describe": "describe_us", "k_knn2": "knn2_us", "select_host": "select_us"}
+                "k_describe_fused": "describe_us", "k_knn2": "knn2_us", "select_host": "select_us"}
 
 
 def algorithmic_bytes(kernel, S, S0, s_last, K, Kc, buckets):
@@ -55,7 +55,7 @@ def algorithmic_bytes(kernel, S, S0, s_last, K, Kc, buckets):
         return (S - s_last) + (S - S0)
     if kernel == "k_blur":
         return 2 * S
-    if kernel == "k_describe":        # k_describe_fused: the 33 x 33 source window of each keypoint in, 32 bytes out
+    if kernel == "k_describe_fused":  # the 33 x 33 source window of each keypoint in, 32 bytes out
         return K * (33 * 33 + 32)
     if kernel == "k_knn2":            # per pair: both descriptor sets once + 8-byte partial per query
         return 2 * K * 32 + K * 16
