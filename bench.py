@@ -43,7 +43,7 @@ CONFIGS = {
 IMAGES_PER_LAUNCH = 128     # camera images per slot job (32 four-camera or 16 eight-camera rig frames)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 GPU_KERNELS = ("k_resize", "k_fast_cells", "k_compact", "k_describe_fused", "k_knn2")   # k_blur: only with MCORB_BLUR_PLANES / orientation
-TIMING_FIELD = {"k_resize": "pyramid_us", "k_fast_cells": "fast_us", "k_compact": "compact_us", "k_blur": "blur_us",
+TIMING_FIELD = {"k_resize": "pyramid_us", "k_fast_cells": "fast_us", "k_compact": "compact_us",
                 "k_describe_fused": "describe_us", "k_knn2": "knn2_us", "select_host": "select_us"}
 
 
