@@ -102,6 +102,34 @@ def test_golden_fixtures(mc, name):
 # --------------------------------------------------------------------------------------------
 # the reference's operator surface: ORBextractor / MultiCameraFrame mirrors
 # --------------------------------------------------------------------------------------------
+def test_plane_based_descriptor_path_equals_fused(mc, monkeypatch):
+    """MCORB_BLUR_PLANES=1 (k_blur over whole levels into the tiled planes + k_describe) against the default
+    (k_describe_fused blurs only around the kept keypoints) and against the golden descriptors."""
+    g = np.load(os.path.join(HERE, "golden", "rig2_160x120_n300_l4.npz"))
+    ncams, w, h, nfeat, nlev, frame = (int(v) for v in g["meta"])
+    imgs = [mc.synth_rig_frame(frame, ncams, c, w, h) for c in range(ncams)]
+    imgs720 = [mc.synth_rig_frame(5, 2, c, 1280, 720) for c in range(2)]
+    got = {}
+    for mode in ("fused", "planes"):
+        if mode == "planes":
+            monkeypatch.setenv("MCORB_BLUR_PLANES", "1")
+        rig = mc.Rig(ncams, w, h, 1, 1, nfeatures=nfeat, nlevels=nlev)
+        rig.upload(imgs)
+        rig.process_submit(1)
+        rig.process_wait()
+        for c in range(ncams):
+            assert np.array_equal(rig.features(c)[2], g["desc_%d" % c]), (mode, c)
+        rig.close()
+        big = mc.Rig(2, 1280, 720, 1, 1, nfeatures=2000)
+        big.upload(imgs720)
+        big.process_submit(1)
+        big.process_wait()
+        got[mode] = [big.features(c)[2].copy() for c in range(2)] + [big.level(0, l, blurred=True).copy() for l in (0, 3, 7)]
+        big.close()
+    for a, b in zip(got["fused"], got["planes"]):   # descriptors, and the blurred planes made on demand vs with the job
+        assert np.array_equal(a, b)
+
+
 def test_orbextractor_mirror_and_error_behaviour(mc):
     ext = mc.ORBextractor(1000, 1.2, 8, 20, 7)
     ora = O.OracleExtractor(1000)
