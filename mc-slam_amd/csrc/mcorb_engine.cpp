@@ -345,6 +345,11 @@ static int usable_cores()
         if (fp) fclose(fp);
     }
     if (quota > 0 && period > 0) n = std::min(n, (int)std::max(1LL, quota / period));
+    // one process per GPU on a multi-GPU node: the ranks of the node share those cores (torch.distributed.run exports
+    // LOCAL_WORLD_SIZE; MCORB_LOCAL_RANKS says the same for other launchers)
+    const char *lr = getenv("MCORB_LOCAL_RANKS") ? getenv("MCORB_LOCAL_RANKS") : getenv("LOCAL_WORLD_SIZE");
+    const int ranks = lr ? atoi(lr) : 1;
+    if (ranks > 1) n = std::max(2, n / ranks);
     return n;
 }
 
@@ -433,9 +438,10 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     // whole process was stalled for 5-15 ms each time, 15 % of the throughput).  Default: what is left after the drivers
     // and the caller, at most one worker per image of a batch and at most 16.
     const int cores = usable_cores();
-    int nthreads = p.host_threads > 0 ? p.host_threads : cores - nslots - 2;
-    bool crowded = false;   // too few cores for spinning drivers: they sleep on their events instead
-    if (p.host_threads <= 0 && nthreads < 4) { crowded = true; nthreads = cores - 2; }
+    const char *sync_env0 = getenv("MCORB_SYNC");
+    bool crowded = sync_env0 ? !strcmp(sync_env0, "block") : nslots > 8;   // drivers sleep on their events: they take no core
+    int nthreads = p.host_threads > 0 ? p.host_threads : (crowded ? cores - 3 : cores - nslots - 2);
+    if (p.host_threads <= 0 && !crowded && nthreads < 4) { crowded = true; nthreads = cores - 3; }   // too few cores for spinning drivers
     if (p.host_threads <= 0) nthreads = std::max(2, std::min(nthreads, std::min(max_images, 16)));
     if (getenv("MCORB_HOST_THREADS")) nthreads = atoi(getenv("MCORB_HOST_THREADS"));
     nthreads = std::max(1, std::min(nthreads, 64));
@@ -461,7 +467,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         // measured 2-4 % faster than interrupt-driven waits at 6 slots; with many slots the spinning drivers would take
         // the cores the selection workers need, so those rigs sleep instead.  MCORB_SYNC=block|spin overrides.
         const char *sync_env = getenv("MCORB_SYNC");
-        const bool blocking = sync_env ? !strcmp(sync_env, "block") : (nslots > 8 || crowded);
+        const bool blocking = sync_env ? !strcmp(sync_env, "block") : crowded;
         HIPCHK(hipEventCreateWithFlags(&s->ev_x, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&s->ev_c, hipEventDefault));
         HIPCHK(hipEventCreateWithFlags(&s->ev_e, hipEventDefault));
