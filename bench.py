@@ -206,12 +206,25 @@ def main():
         my_frames, sets = shard.a2a_match_sets(rank, N, NCAMS, total_frames)   # set index of (f, c) inside the received block
         assert len(my_frames) == F
         torch.cuda.synchronize()   # the zero fills above ran on torch's stream; the engine writes these tensors from its own
-        tstream = torch.cuda.current_stream().cuda_stream          # raw HIP stream the collectives are ordered on
+        # The collectives are ordered on a stream of their own.  torch's default stream is the NULL stream, whose handle is
+        # 0: passed to the engine that reads as "no stream" and the hand-offs fall back to synchronising the host (which
+        # round 2's first measurements did without saying so: 0.55 ms of the main thread per export).
+        cstream = torch.cuda.Stream()
+        tstream = cstream.cuda_stream                               # raw HIP stream handle, never 0
+        assert tstream != 0
         exchange_bytes = nsets * (kcap * 32 + 4)
 
+    hostprof = {} if os.environ.get("MCORB_BENCH_PROF") else None   # main-thread seconds per phase of the sharded loop
+
+    def hp(name, t0):
+        if hostprof is not None:
+            hostprof[name] = hostprof.get(name, 0.0) + time.perf_counter() - t0
+
     def extract_submit(g):
+        t0 = time.perf_counter()
         for i in range(SG):
             rig.extract_submit(per_slot, slot=g * SG + i)
+        hp("extract_submit", t0)
 
     def exchange_and_match(g):
         """Waits for group g's extraction, exchanges the descriptors and queues the matching; match_finish(g) collects it.
@@ -231,18 +244,29 @@ def main():
         else:
             for i in range(SG):
                 s = g * SG + i
+                t0 = time.perf_counter()
                 rig.extract_wait(slot=s)
+                hp("extract_wait", t0)
+                t0 = time.perf_counter()
                 rig.export_descriptors_dev(local_desc[g][i * per_slot].data_ptr(), local_cnt[g][i * per_slot:].data_ptr(), per_slot,
                                            slot=s, then_stream=tstream)
-            dist.all_to_all_single(recv_desc[g], local_desc[g], recv_splits, send_splits)   # the exchange step (RCCL over xGMI)
-            dist.all_to_all_single(recv_cnt[g], local_cnt[g], recv_splits, send_splits)
+                hp("export", t0)
+            t0 = time.perf_counter()
+            with torch.cuda.stream(cstream):
+                dist.all_to_all_single(recv_desc[g], local_desc[g], recv_splits, send_splits)   # the exchange step (RCCL over xGMI)
+                dist.all_to_all_single(recv_cnt[g], local_cnt[g], recv_splits, send_splits)
+            hp("all_to_all", t0)
+        t0 = time.perf_counter()
         for i in range(SG):                                     # this rank's frames, split over the group's slots
             rig.match_external_dev_submit(recv_desc[g].data_ptr(), recv_cnt[g].data_ptr(), nsets, sets[i * fps:(i + 1) * fps],
                                           slot=g * SG + i, after_stream=None if gloo else tstream)
+        hp("match_submit", t0)
 
     def match_finish(g):
+        t0 = time.perf_counter()
         for i in range(SG):
             rig.match_wait(slot=g * SG + i)
+        hp("match_wait", t0)
 
     def barrier():
         if dist is not None:
@@ -305,10 +329,16 @@ def main():
 
     def timed_region(nsteps, timed, stage=None):
         barrier()
+        if hostprof is not None:
+            hostprof.clear()
         t0 = time.perf_counter()
         run_steps(nsteps, timed, stage)
+        t1 = time.perf_counter()
         barrier()
         dt = time.perf_counter() - t0
+        if hostprof is not None and rank == 0:
+            print("[bench] main thread, %d steps, %.1f ms (+%.1f ms closing barrier): " % (nsteps, (t1 - t0) * 1e3, (dt - (t1 - t0)) * 1e3) +
+                  ", ".join("%s %.1f ms" % (k, v * 1e3) for k, v in sorted(hostprof.items(), key=lambda x: -x[1])), file=sys.stderr)
         if dist is not None:
             tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if gloo else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -195,6 +195,8 @@ int mcorb_rig_match_external_submit(mcorb_rig *r, int slot, const void *desc_dev
  * on; NULL = block until the copies are done) wait for them;
  * _match_external_dev_submit takes the counts from device memory and lets the slot's stream wait for everything
  * enqueued so far on `after_stream` (the collective; NULL = the caller has synchronised already).
+ * The legacy NULL stream cannot be named here (its handle IS NULL): issue the collective on a stream created with
+ * hipStreamCreate / torch.cuda.Stream().
  * An external block holds at most max(4096, 64 x images per slot) sets (MCORB_E_ARG beyond). */
 int mcorb_rig_export_descriptors_dev(mcorb_rig *r, int slot, void *dst_dev, int32_t *counts_dev, int nimg, void *then_stream);
 int mcorb_rig_match_external_dev_submit(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts_dev, int ntotal,

@@ -324,6 +324,18 @@ void WorkerPool::parallel_for(int n, const std::function<void(int, int)> &fn, in
 // ---------------------------------------------------------------------------
 // Rig
 // ---------------------------------------------------------------------------
+hipError_t Rig::wait_event(hipEvent_t ev) const
+{
+    if (wait_mode != 2) return hipEventSynchronize(ev);   // spins, or sleeps on the interrupt (event flag)
+    for (int i = 0;; i++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e != hipErrorNotReady) return e;
+        if (i < 4) { std::this_thread::yield(); continue; }   // a wait that is almost over
+        timespec ts = {0, 30000};
+        nanosleep(&ts, nullptr);
+    }
+}
+
 // Cores this process can actually use: hardware threads, cut down to the scheduler affinity mask and to the cgroup CPU
 // quota (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us), whichever is smallest.
 static int usable_cores()
@@ -438,10 +450,16 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     // whole process was stalled for 5-15 ms each time, 15 % of the throughput).  Default: what is left after the drivers
     // and the caller, at most one worker per image of a batch and at most 16.
     const int cores = usable_cores();
+    // How the slot drivers wait for the GPU.  hipEventSynchronize spins: one core per slot, ~60 % of it spent doing
+    // nothing at six slots -- cores the selection needs (at 31 k frames/s the selection alone keeps 8.7 cores busy and
+    // the GPU box grants 16).  HIP's interrupt-driven wait (hipEventBlockingSync) measured no cheaper in CPU time.
+    // Default with several slots: poll hipEventQuery with 30 us sleeps in between (a few % of a core; the added latency
+    // is hidden behind the other slots).  One slot = latency mode: spin.  MCORB_SYNC=spin|block|poll overrides.
     const char *sync_env0 = getenv("MCORB_SYNC");
-    bool crowded = sync_env0 ? !strcmp(sync_env0, "block") : nslots > 8;   // drivers sleep on their events: they take no core
-    int nthreads = p.host_threads > 0 ? p.host_threads : (crowded ? cores - 3 : cores - nslots - 2);
-    if (p.host_threads <= 0 && !crowded && nthreads < 4) { crowded = true; nthreads = cores - 3; }   // too few cores for spinning drivers
+    wait_mode = nslots > 1 ? 2 : 0;
+    if (sync_env0) wait_mode = !strcmp(sync_env0, "block") ? 1 : (!strcmp(sync_env0, "poll") ? 2 : 0);
+    const bool crowded = wait_mode == 1;   // events created with hipEventBlockingSync
+    int nthreads = p.host_threads > 0 ? p.host_threads : (wait_mode == 0 ? cores - nslots - 2 : cores - 4);
     if (p.host_threads <= 0) nthreads = std::max(2, std::min(nthreads, std::min(max_images, 16)));
     if (getenv("MCORB_HOST_THREADS")) nthreads = atoi(getenv("MCORB_HOST_THREADS"));
     nthreads = std::max(1, std::min(nthreads, 64));
@@ -694,7 +712,7 @@ int Rig::execute(Slot &s, const Job &j)
         st = enqueue_match(s, j, false);
         if (st == MCORB_OK) {
             hipError_t e = hipEventRecord(s.ev[10], s.st);
-            if (e == hipSuccess) e = hipEventSynchronize(s.ev[10]);
+            if (e == hipSuccess) e = wait_event(s.ev[10]);
             if (e != hipSuccess) { set_error(hipGetErrorString(e)); st = MCORB_E_HIP; }
         }
         if (st == MCORB_OK) st = finish_match(s, j);
@@ -783,7 +801,7 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
 
 int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
 {
-    HIPCHK(hipEventSynchronize(s.ev[3]));
+    HIPCHK(wait_event(s.ev[3]));
     if (s.h_overflow[0]) {
         set_error("candidate list of a sparse level does not fit the host buffer (raise mcorb_params.cand_cap)");
         (void)hipStreamSynchronize(s.st);
@@ -893,8 +911,8 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s.ev[10], s.st));
     HIPCHK(hipEventRecord(s.ev[11], s.st_dma));
-    HIPCHK(hipEventSynchronize(s.ev[10]));   // events, not streams: the compute stream may be shared between slots
-    HIPCHK(hipEventSynchronize(s.ev[11]));
+    HIPCHK(wait_event(s.ev[10]));   // events, not streams: the compute stream may be shared between slots
+    HIPCHK(wait_event(s.ev[11]));
     if (params.orientation)
         for (int m = 0; m < nimg; m++)
             for (size_t k = 0; k < s.kps[m].size(); k++) s.kps[m][k].angle = s.h_angles[(size_t)m * geom.kcap + k];

@@ -205,6 +205,8 @@ public:
     std::vector<Slot *> slots;
     WorkerPool *pool = nullptr;
     int pool_threads = 0;
+    int wait_mode = 0;         // how a thread waits for a HIP event: 0 spin (hipEventSynchronize), 1 interrupt-driven, 2 poll + short sleeps
+    hipError_t wait_event(hipEvent_t ev) const;
     std::vector<SelectScratch *> scratch;   // one per worker
 
     void merge_tracks(Slot &s, int f, const EpipolarGate *gate, std::vector<int32_t> &tr, int &mergeable_out) const;
