@@ -1312,48 +1312,80 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
         fill(0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        // The tile loop is software-pipelined: while the matrix pipe multiplies tile t+1 (into a second accumulator set),
+        // the vector ALU folds tile t's keys into the running top-2.  A wave issues in order, and a multiply that
+        // accumulates into the register of the one two instructions back stalls the wave until that one is done -- so the
+        // top-2 instructions are placed BETWEEN the multiplies in program order (two multiplies, then the eight vector
+        // instructions of four keys; sched_group_barrier keeps the compiler from regrouping them).  Without this the two
+        // pipes took turns: 92 us of MFMA + 75 us of VALU = the 166 us the kernel needed.
+        auto fold1 = [&](int u, int x) {
+            k1[u] = med3_i32(k0[u], k1[u], x);   // second largest of {k0, k1, x} (k0 >= k1)
+            k0[u] = max(k0[u], x);
+        };
+        auto top2 = [&](const v16i (&acc)[kKnnQT]) {
+#pragma unroll
+            for (int u = 0; u < kKnnQT; u++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) fold1(u, acc[u][e]);
+        };
+        auto mm_fold = [&](const uint4 *S, int tl, int tb, v16i (&acc)[kKnnQT], const v16i (&old)[kKnnQT]) {
+#pragma unroll
+            for (int u = 0; u < kKnnQT; u++) acc[u] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+            // the train fragments are read from LDS two steps ahead of the multiplies that use them: read right in front of
+            // its use, every step began with ~100 cycles of LDS latency (matrix pipe 63 % busy)
+            v4i Af[3];
+            Af[0] = __builtin_bit_cast(v4i, S[(tl * 8) * 64 + lane]);
+            Af[1] = __builtin_bit_cast(v4i, S[(tl * 8 + 1) * 64 + lane]);
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                if (s + 2 < 8) Af[(s + 2) % 3] = __builtin_bit_cast(v4i, S[(tl * 8 + s + 2) * 64 + lane]);
+#pragma unroll
+                for (int u = 0; u < kKnnQT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af[s % 3], Bf[u][s], acc[u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < kKnnQT; u++) {
+                    fold1(u, old[u][2 * s]);
+                    fold1(u, old[u][2 * s + 1]);
+                }
+                if (s + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the ds_read for step s + 2
+                __builtin_amdgcn_sched_group_barrier(0x008, kKnnQT, 0);      // this step's multiplies
+                __builtin_amdgcn_sched_group_barrier(0x002, 4 * kKnnQT, 0);  // four keys' worth of top-2
+            }
+            {   // ninth K-step, train side: 8191 - (index inside the chunk) as two digits of base 64
+                const int iv = 8191 - (tb + (lane & 31));
+                const v4i A9 = {half == 0 ? ((iv & 63) | ((iv >> 6) << 8)) : 0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < kKnnQT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A9, B9, acc[u], 0, 0, 0);
+            }
+            if (tb + 32 > tn) {   // last tile of the set: rows past the end hold stale bytes
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const bool ok = tb + (e & 3) + 8 * (e >> 2) + 4 * half < tn;   // C/D layout: row = (e&3) + 8 (e>>2) + 4 (lane>>5)
+#pragma unroll
+                    for (int u = 0; u < kKnnQT; u++) acc[u][e] = ok ? acc[u][e] : kMin;
+                }
+            }
+        };
+        static_assert(kKnnStageTiles == 2, "the pipelined tile loop is written for two tiles per stage");
+        v16i accA[kKnnQT], accB[kKnnQT];
+        const v16i allMin = {kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin};
+#pragma unroll
+        for (int u = 0; u < kKnnQT; u++) accA[u] = allMin;   // "nothing pending": folding it changes nothing
         for (int st = 0; st < nstage; st++) {
             if (st + 1 < nstage) fill(st + 1, (st + 1) & 1);   // travels while this stage is multiplied (that buffer was last read a barrier ago)
             const uint4 *S = stage[st & 1];
+            const int tb0 = st * kKnnStageTiles * 32, tb1 = tb0 + 32;   // first trains of the two tiles, relative to t0 (tb0 < tn)
+            mm_fold(S, 0, tb0, accB, accA);
+            if (tb1 < tn) {
+                mm_fold(S, 1, tb1, accA, accB);
+            } else {
+                top2(accB);
 #pragma unroll
-            for (int tl = 0; tl < kKnnStageTiles; tl++) {
-                const int tb = (st * kKnnStageTiles + tl) * 32;   // first train of the tile, relative to t0
-                if (tb >= tn) break;
-                v16i acc[kKnnQT];
-#pragma unroll
-                for (int u = 0; u < kKnnQT; u++) acc[u] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int s = 0; s < 8; s++) {
-                    const v4i A = __builtin_bit_cast(v4i, S[(tl * 8 + s) * 64 + lane]);
-#pragma unroll
-                    for (int u = 0; u < kKnnQT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A, Bf[u][s], acc[u], 0, 0, 0);
-                }
-                {   // ninth K-step, train side: 8191 - (index inside the chunk) as two digits of base 64
-                    const int iv = 8191 - (tb + (lane & 31));
-                    const v4i A9 = {half == 0 ? ((iv & 63) | ((iv >> 6) << 8)) : 0, 0, 0, 0};
-#pragma unroll
-                    for (int u = 0; u < kKnnQT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A9, B9, acc[u], 0, 0, 0);
-                }
-                if (tb + 32 > tn) {   // last tile of the set: rows past the end hold stale bytes
-#pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        const bool ok = tb + (e & 3) + 8 * (e >> 2) + 4 * half < tn;   // C/D layout: row = (e&3) + 8 (e>>2) + 4 (lane>>5)
-#pragma unroll
-                        for (int u = 0; u < kKnnQT; u++) acc[u][e] = ok ? acc[u][e] : kMin;
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < kKnnQT; u++)
-#pragma unroll
-                    for (int e = 0; e < 16; e++) {
-                        const int x = acc[u][e];
-                        k1[u] = med3_i32(k0[u], k1[u], x);   // second largest of {k0, k1, x} (k0 >= k1)
-                        k0[u] = max(k0[u], x);
-                    }
+                for (int u = 0; u < kKnnQT; u++) accA[u] = allMin;
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next stage has landed
             __syncthreads();
         }
+        top2(accA);
     }
     // the two lane halves hold different train rows of the same query columns: merge, convert, store
     uint2 *out = part + ((size_t)pair * nchunks + chunk) * kcap;
