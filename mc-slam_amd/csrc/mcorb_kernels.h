@@ -29,7 +29,8 @@ constexpr int kFastMaxGroups = 24;   // 4-px groups of an LDS tile row (pitch <=
 // first group g0) the LDS byte offset | group << 16 of item i = (row i / ng, group i % ng); returns the row stride of the
 // table (entries per (ng, g0))
 int fast_item_table(const Geom &g, std::vector<uint32_t> &tab);
-void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, const uint32_t *tab, int tabStride,
+int fast_cell_table(const Geom &g, std::vector<uint32_t> &tab);   // appends the per-cell records, returns their dword offset
+void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, const uint32_t *tab, int tabStride, int cellRecOff,
                  uint32_t *cell_kp, int *cell_cnt, int nimg);
 // tbl: device table blocks (tbl_ints(g.bucketTotal) ints per image, layout in mcorb_common.h); cand / overflow: host-mapped
 // lut: path-code tables (LevelGeom::lutx / luty)

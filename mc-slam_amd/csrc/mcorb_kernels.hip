@@ -231,36 +231,57 @@ struct FastCell {      // wave-uniform description of one cell
     int pitch;         // HBM row pitch of the level
 };
 
-__device__ __forceinline__ void fast_cell_setup(const uint8_t *pyr, const Geom &g, int img, int cell, FastCell &C)
+// The cell's record comes from a host-built table (fast_cell_table(), 8 dwords per cell of an image, behind the item
+// tables): one scalar load instead of a seven-step search for the cell's level, a division and ~40 scalar instructions of
+// ROI arithmetic at the head of each of the 254 k waves of a launch.
+constexpr int kFastCellRecDw = 8;
+__device__ __forceinline__ void fast_cell_setup(const uint8_t *pyr, const Geom &g, int img, int cell, const uint32_t *__restrict__ rec, FastCell &C)
 {
-    C.on = 0; C.cell = cell; C.ph = 0; C.wi = 0; C.hi = 0; C.rows = 0; C.g0 = 0; C.ng = 1; C.org = 0; C.src = pyr; C.pitch = 0;
-    int level = 0;
-#pragma unroll 1
-    for (int l = 1; l < g.nlevels; l++)
-        if (cell >= g.lv[l].cell0) level = l;
-    const LevelGeom &L = g.lv[level];
-    const int cl = cell - L.cell0;
-    const int ci = (int)(((float)cl + 0.5f) * __builtin_amdgcn_rcpf((float)L.nCols)), cj = cl - ci * L.nCols;
-    // cell ROI exactly as the reference builds it (float there, exact in int)
-    const int iniY = kMinBorder + ci * L.hCell;
-    int maxY = iniY + L.hCell + 6;
-    const int iniX = kMinBorder + cj * L.wCell;
-    int maxX = iniX + L.wCell + 6;
-    const bool skip = (iniY >= L.maxBorderY - 3) || (iniX >= L.maxBorderX - 6);
-    if (maxY > L.maxBorderY) maxY = L.maxBorderY;
-    if (maxX > L.maxBorderX) maxX = L.maxBorderX;
-    const int cols = maxX - iniX, rows = maxY - iniY;
-    C.wi = cols - 6;   // FAST evaluates ROI columns 3..cols-4, rows 3..rows-4
-    C.hi = rows - 6;
-    C.rows = rows;
-    C.ph = iniX & 3;
-    C.g0 = (C.ph + 3) >> 2;
-    C.ng = ((C.ph + 2 + C.wi) >> 2) - C.g0 + 1;
-    C.on = !(skip || C.wi <= 0 || C.hi <= 0);
-    if (!C.on) C.ng = 1;
-    C.org = ((uint32_t)(ci * L.hCell) << 20) + ((uint32_t)(cj * L.wCell - C.ph) << 8);
-    C.pitch = L.pitch;
-    C.src = pyr + (size_t)img * g.imgBytes + L.off + (size_t)iniY * L.pitch + (iniX - C.ph);
+    const uint4 r = *reinterpret_cast<const uint4 *>(rec + (size_t)cell * kFastCellRecDw);
+    const uint32_t r4 = rec[(size_t)cell * kFastCellRecDw + 4];
+    C.cell = cell;
+    C.src = pyr + (size_t)img * g.imgBytes + r.x;
+    C.org = r.y;
+    C.pitch = (int)r.z;
+    C.rows = (int)(r.w & 0xff);
+    C.wi = (int)((r.w >> 8) & 0xff);
+    C.hi = (int)((r.w >> 16) & 0xff);
+    C.on = (int)((r.w >> 24) & 1);
+    C.ph = (int)((r.w >> 25) & 3);
+    C.g0 = (int)(r4 & 0xff);
+    C.ng = (int)(r4 >> 8);
+}
+
+// host: the records, exactly the reference's ROI arithmetic (ORBextractor.cpp:804-833; float there, exact in int)
+int fast_cell_table(const Geom &g, std::vector<uint32_t> &tab)
+{
+    const int off = (int)tab.size();
+    tab.resize(tab.size() + (size_t)g.cells * kFastCellRecDw, 0u);
+    for (int level = 0; level < g.nlevels; level++) {
+        const LevelGeom &L = g.lv[level];
+        for (int cl = 0; cl < L.nCols * L.nRows; cl++) {
+            const int ci = cl / L.nCols, cj = cl - ci * L.nCols;
+            const int iniY = kMinBorder + ci * L.hCell;
+            int maxY = iniY + L.hCell + 6;
+            const int iniX = kMinBorder + cj * L.wCell;
+            int maxX = iniX + L.wCell + 6;
+            const bool skip = (iniY >= L.maxBorderY - 3) || (iniX >= L.maxBorderX - 6);
+            if (maxY > L.maxBorderY) maxY = L.maxBorderY;
+            if (maxX > L.maxBorderX) maxX = L.maxBorderX;
+            const int cols = maxX - iniX, rows = maxY - iniY;
+            const int wi = cols - 6, hi = rows - 6;   // FAST evaluates ROI columns 3..cols-4, rows 3..rows-4
+            const int ph = iniX & 3, g0 = (ph + 3) >> 2;
+            const bool on = !(skip || wi <= 0 || hi <= 0);
+            const int ng = on ? ((ph + 2 + wi) >> 2) - g0 + 1 : 1;
+            uint32_t *r = tab.data() + off + (size_t)(L.cell0 + cl) * kFastCellRecDw;
+            r[0] = on ? (uint32_t)(L.off + (size_t)iniY * L.pitch + (iniX - ph)) : 0u;
+            r[1] = ((uint32_t)(ci * L.hCell) << 20) + ((uint32_t)(cj * L.wCell - ph) << 8);
+            r[2] = (uint32_t)L.pitch;
+            r[3] = on ? ((uint32_t)rows | ((uint32_t)wi << 8) | ((uint32_t)hi << 16) | (1u << 24) | ((uint32_t)ph << 25)) : 0u;
+            r[4] = (uint32_t)g0 | ((uint32_t)ng << 8);
+        }
+    }
+    return off;
 }
 
 // Work-list capacity.  A trip of pass 1 appends at most 256 entries and runs only while 256 more still fit, so the
@@ -377,7 +398,7 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *lo)   // lo = &pixe
 // [work list, cap x 2 B] = 5.5 KiB at TP = 48: 29 waves per CU (the measured optimum); <= 80 SGPRs and <= 64 VGPRs leave 8 waves per SIMD.
 template <int TP>
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom g, int iniTh, int minTh,
-                                                   int tileB, int scB, int cap, const uint32_t *__restrict__ tab, int tabStride,
+                                                   int tileB, int scB, int cap, const uint32_t *__restrict__ tab, int tabStride, int cellRecOff,
                                                    uint32_t *__restrict__ cell_kp, int *__restrict__ cell_cnt)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -392,7 +413,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     const int lane = threadIdx.x;
     const int img = blockIdx.y;
     FastCell C;
-    fast_cell_setup(pyr, g, img, __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x)), C);
+    fast_cell_setup(pyr, g, img, __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x)), tab + cellRecOff, C);
     int *out_cnt = cell_cnt + (size_t)img * g.cells + C.cell;
     if (!C.on) {
         if (lane == 0) *out_cnt = 0;
@@ -1618,7 +1639,7 @@ int fast_item_table(const Geom &g, std::vector<uint32_t> &tab)
     return stride;
 }
 
-void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, const uint32_t *tab, int tabStride,
+void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, const uint32_t *tab, int tabStride, int cellRecOff,
                  uint32_t *cell_kp, int *cell_cnt, int nimg)
 {
     // LDS per wave: the tile, the score map (four rows fewer), the column masks, the bounded survivor list
@@ -1631,9 +1652,9 @@ void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, i
     dim3 grid(g.cells, nimg);
     if (iniTh < 0) iniTh = 0;   // (the kernel's column masks rely on thresholds >= 0; FAST thresholds are)
     if (minTh < 0) minTh = 0;
-    if (tp == 48) hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, tab, tabStride, cell_kp, cell_cnt);
-    else if (tp == 64) hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, tab, tabStride, cell_kp, cell_cnt);
-    else hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, tab, tabStride, cell_kp, cell_cnt);
+    if (tp == 48) hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, tab, tabStride, cellRecOff, cell_kp, cell_cnt);
+    else if (tp == 64) hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, tab, tabStride, cellRecOff, cell_kp, cell_cnt);
+    else hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, tab, tabStride, cellRecOff, cell_kp, cell_cnt);
 }
 
 void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt, const Geom &g, const uint16_t *lut,
