@@ -389,7 +389,7 @@ def main():
     unit_bytes = algorithmic_bytes(dominant, Spx, S0, s_last, K, Kc, info["bucket_total"])
     achieved = unit_bytes * units / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
     # PMC-derived HBM bytes per launch: only if profiles/traffic.json was measured on exactly these kernels
-    traffic, traffic_note = None, "profiles/traffic.json absent"
+    traffic, traffic_note, valu_insts = None, "profiles/traffic.json absent", None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
@@ -402,6 +402,7 @@ def main():
             else:
                 traffic = int(tj[dominant]["bytes_per_image"] * nimg_launch)
                 traffic_note = tj.get("_correction", "")
+                valu_insts = tj[dominant].get("valu_insts_per_launch")
         except Exception as e:      # noqa: BLE001
             traffic_note = "profiles/traffic.json unreadable: %s" % e
     out = {
@@ -423,6 +424,13 @@ def main():
                              "isolated_* is the same kernel with one job in flight (median of %d)" % (S, args.iso_jobs)},
         "kernel_us_per_step": {k: round(v / args.steps / len(dts), 2) for k, v in ksum.items()},
     }
+    if valu_insts:
+        # the bound that actually holds the dominant kernel: wave64 vector instructions issue at one per 4 cycles per SIMD
+        # (tools/valu_rates.hip); SQ_INSTS_VALU per launch from profiles/ (same sha check as the traffic figure)
+        SIMDS, CLK_HZ = 1024, 2.4e9
+        floor_us = valu_insts * 4 / SIMDS / CLK_HZ * 1e6
+        out["roofline"]["valu"] = {"insts_per_launch": int(valu_insts), "cycles_per_inst": 4, "simds": SIMDS, "clock_ghz": 2.4,
+                                   "floor_us": round(floor_us, 1), "frac_in_flight": round(floor_us / avg_us, 3)}
     if DIST:
         out["exchange"] = {"collective": "all_to_all_single (uneven splits)", "bytes_sent_per_rank_per_step": int(exchange_bytes),
                            "send_splits_rank0": send_splits}
@@ -430,6 +438,8 @@ def main():
         ia = unit_bytes * units / (iso[dominant] * 1e-6) / 1e9
         out["roofline"].update({"isolated_launch_us": round(iso[dominant], 2), "isolated_achieved": round(ia, 2),
                                 "isolated_frac": round(ia / HBM_PEAK_GBS, 5)})
+        if "valu" in out["roofline"]:
+            out["roofline"]["valu"]["frac_isolated"] = round(out["roofline"]["valu"]["floor_us"] / iso[dominant], 3)
         out["kernel_us_per_launch_isolated"] = {k: round(v, 2) for k, v in iso.items()}
         # every kernel against its own algorithmic bytes (isolated): where the path stands as a whole
         out["roofline_all_kernels_isolated"] = {

@@ -42,12 +42,23 @@ out = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZ
        "_correction": "bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024: FETCH_SIZE reads exactly 1/2 of a known byte count for 16-, 4- "
                       "and 1-byte-per-lane streaming reads on this gfx950 (profiles/%s_fetch_calibration.txt), WRITE_SIZE is exact" % tag,
        "kernels_sha256_16": sha, "config": bench["config"]["name"], "round": tag}
+# vector instructions per launch (SQ_INSTS_VALU), for the instruction-issue bound bench.py reports beside the HBM one
+valu, cur = {}, None
+sq = os.path.join(P, tag + "_pmc_sq_counters.txt")
+if os.path.exists(sq):
+    for line in open(sq):
+        if not line.startswith(" "):
+            cur = line.split()[0]
+        elif line.split()[0] == "SQ_INSTS_VALU" and cur not in valu:
+            valu[cur] = float(line.split()[2])
 for k in sorted(set(f) & set(w)):
     if not k.startswith("k_"):
         continue
     mult = 7 if k == "k_resize" else 1   # 7 level launches per image batch; the summary holds the per-launch mean
     out[k] = {"bytes_per_image": int((2 * f[k] + w[k]) * 1024 * mult / NIMG), "fetch_size_kib_per_launch_raw": f[k],
               "write_size_kib_per_launch": w[k], "images_per_launch": NIMG}
+    if k in valu:
+        out[k]["valu_insts_per_launch"] = int(valu[k] * mult)
     if mult > 1:
         out[k]["note"] = "sum of the 7 level launches"
 json.dump(out, open(os.path.join(P, "traffic.json"), "w"), indent=1)

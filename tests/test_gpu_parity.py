@@ -130,6 +130,29 @@ def test_plane_based_descriptor_path_equals_fused(mc, monkeypatch):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("mode", ["spin", "block", "poll"])
+def test_driver_wait_modes_give_the_same_frames(mc, monkeypatch, mode):
+    """MCORB_SYNC only changes how the slot drivers wait for the GPU (hipEventSynchronize, interrupt-driven, hipEventQuery
+    + sleeps): three slots in flight, every mode must return the golden fixture's features and tracks."""
+    g = np.load(os.path.join(HERE, "golden", "rig2_160x120_n300_l4.npz"))
+    ncams, w, h, nfeat, nlev, frame = (int(v) for v in g["meta"])
+    monkeypatch.setenv("MCORB_SYNC", mode)
+    rig = mc.Rig(ncams, w, h, 1, 3, nfeatures=nfeat, nlevels=nlev)
+    imgs = [mc.synth_rig_frame(frame, ncams, c, w, h) for c in range(ncams)]
+    for rep in range(3):
+        for s in range(3):
+            rig.upload(imgs, slot=s)
+            rig.process_submit(1, slot=s)
+        for s in range(3):
+            rig.process_wait(slot=s)
+            for c in range(ncams):
+                mono, k, d = rig.features(c, slot=s)
+                assert np.array_equal(d, g["desc_%d" % c]) and np.array_equal(k["x"], g["kps_%d" % c]["x"])
+            tr, mg = rig.tracks(0, slot=s)
+            assert np.array_equal(tr, g["tracks"]) and mg == int(g["mergeable"][0])
+    rig.close()
+
+
 def test_orbextractor_mirror_and_error_behaviour(mc):
     ext = mc.ORBextractor(1000, 1.2, 8, 20, 7)
     ora = O.OracleExtractor(1000)
