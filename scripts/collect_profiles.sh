@@ -8,7 +8,7 @@ mkdir -p $O
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
 ONE="--steps 3 --warmup 1 --repeats 1 --no-cpu --no-latency --no-staging --slots 1 --frames 32 --iso-jobs 1"
-timeout -k 10 400 python3 bench.py 2>$O/bench.err | tail -1 > $O/bench_default.json
+timeout -k 10 400 python3 bench.py 2>$O/bench.err | tail -1 > $O/bench_default.json   # provisional (install_profiles.py reads the launch size from it)
 echo "bench done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_def -o d -- python3 bench.py --no-cpu --no-latency --no-staging --repeats 1 > $O/p_def.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_1s -o s -- python3 bench.py $ONE > $O/p_1s.log 2>&1
@@ -23,4 +23,8 @@ bash scripts/fetch_calib.sh $O/calib > $O/calib.txt 2>&1 || true
 timeout -k 10 200 python3 scripts/bow_rate.py 2>/dev/null | tail -1 > $O/bow_rate.json || true
 cp $(find $O/p_def -name '*kernel_stats.csv' | head -1) $O/stats_default.csv
 cp $(find $O/p_1s -name '*kernel_stats.csv' | head -1) $O/stats_1slot.csv
+# the bench line that is kept: run again with traffic.json regenerated from THIS run's counters, so that roofline.traffic and
+# roofline.valu are filled in (bench.py drops them when the kernel sources' sha does not match)
+python3 scripts/install_profiles.py $O ${2:-r02} > /dev/null
+timeout -k 10 400 python3 bench.py 2>$O/bench.err | tail -1 > $O/bench_default.json
 echo collected into $O
