@@ -1,3 +1,4 @@
+# cases for scripts/throttle_matrix.sh <outdir> scripts/throttle_cases.sh: driver wait mode x worker count x slots
 run poll_default MCORB_HOST_PROF=1
 run spin MCORB_SYNC=spin
 run poll_ht10 MCORB_HOST_THREADS=10
