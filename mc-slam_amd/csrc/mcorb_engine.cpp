@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <sched.h>
+#include <sys/prctl.h>
 #include <algorithm>
 #include <new>
 #include <cmath>
@@ -331,7 +332,7 @@ hipError_t Rig::wait_event(hipEvent_t ev) const
         const hipError_t e = hipEventQuery(ev);
         if (e != hipErrorNotReady) return e;
         if (i < 4) { std::this_thread::yield(); continue; }   // a wait that is almost over
-        timespec ts = {0, 30000};
+        timespec ts = {0, 20000};
         nanosleep(&ts, nullptr);
     }
 }
@@ -455,7 +456,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     // How the slot drivers wait for the GPU.  hipEventSynchronize spins: one core per slot, ~60 % of it spent doing
     // nothing at six slots -- cores the selection needs (at 31 k frames/s the selection alone keeps 8.7 cores busy and
     // the GPU box grants 16).  HIP's interrupt-driven wait (hipEventBlockingSync) measured no cheaper in CPU time.
-    // Default with several slots: poll hipEventQuery with 30 us sleeps in between (a few % of a core; the added latency
+    // Default with several slots: poll hipEventQuery with 20 us sleeps in between (a few % of a core; the added latency
     // is hidden behind the other slots).  One slot = latency mode: spin.  MCORB_SYNC=spin|block|poll overrides.
     const char *sync_env0 = getenv("MCORB_SYNC");
     wait_mode = nslots > 1 ? 2 : 0;
@@ -754,6 +755,8 @@ void Rig::driver(Slot *sp)
 {
     Slot &s = *sp;
     (void)hipSetDevice(device);
+    // the polling wait sleeps 20 us at a time: without this the kernel's default 50 us timer slack triples that
+    if (wait_mode == 2) (void)prctl(PR_SET_TIMERSLACK, 2000UL, 0, 0, 0);
     for (;;) {
         Job j;
         {
