@@ -170,10 +170,8 @@ def main():
     fps = F // SG                      # rig frames per slot job
     if fps * SG != F:
         raise SystemExit("--frames must be a multiple of the slots per group (%d)" % SG)
-    if world > 1:
-        # several ranks share the node's CPUs: let the slot driver threads sleep on their HIP events instead of spinning
-        # (2-4 % slower on a single GPU, but N x 8 spinning threads would eat the cores the selection workers need)
-        os.environ.setdefault("MCORB_SYNC", "block")
+    # (several ranks share the node's CPUs: the engine divides its core budget by LOCAL_WORLD_SIZE and its slot drivers poll
+    # their events with short sleeps instead of spinning, so nothing has to be set here)
     rig = mcorb.Rig(NCAMS, W, H, max_frames=fps, nslots=S, nfeatures=NFEAT, device_id=local)
     kcap = rig.kcap
     total_frames = F * N
