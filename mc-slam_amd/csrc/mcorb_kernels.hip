@@ -82,10 +82,11 @@ __global__ __launch_bounds__(256) void k_stage_f32(const float *__restrict__ src
 // ---------------------------------------------------------------------------
 constexpr int kResizeRows = kResizeTileH;   // output rows per workgroup (4 per thread): amortises the window fill + barrier
 
+template <int NF>
 __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom g, int level,
                                                 const ResizeTap *__restrict__ tabs, int srcPitch, int srcRows)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t win[];   // srcRows x srcPitch bytes
+    extern __shared__ __attribute__((aligned(16))) uint8_t win[];   // srcRows x srcPitch bytes + 16 spare
     const LevelGeom &D = g.lv[level];
     const LevelGeom &S = g.lv[level - 1];
     const int img = blockIdx.z;
@@ -112,13 +113,38 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
         uint4 *w128 = reinterpret_cast<uint4 *>(win);
         const int pq = srcPitch >> 4;
         const float rcp_pq = 1.0f / (float)pq;
-        for (int i = tid; i < nr * pq; i += 256) {
-            const int r = (int)(((float)i + 0.5f) * rcp_pq), q = i - r * pq;
-            // rows are 64-byte aligned and padded to a multiple of 64 bytes, so a 16-byte load never leaves the row
-            if (q < nq) w128[i] = *reinterpret_cast<const uint4 *>(sp + (size_t)r * S.pitch + 16 * q);
+        // rows are 64-byte aligned and padded to a multiple of 64 bytes, so a 16-byte load never leaves the row
+        if constexpr (NF > 0) {
+            // every load of the fill is issued before the first LDS store (NF >= ceil(window chunks / 256), launch_pyramid).
+            // As a loop of load - wait - store the fill was four memory round trips in a row per workgroup, on top of the
+            // one for the tap lookups: most of a workgroup's life was spent waiting for them.
+            uint4 v[NF];
+            bool ok[NF];
+#pragma unroll
+            for (int k = 0; k < NF; k++) {
+                const int i = tid + 256 * k, ic = min(i, nr * pq - 1);
+                const int r = (int)(((float)ic + 0.5f) * rcp_pq), q = ic - r * pq;
+                ok[k] = i < nr * pq && q < nq;
+                // unconditional, from a clamped (always valid) address: a load under a branch is waited for at the branch's end
+                v[k] = *reinterpret_cast<const uint4 *>(sp + (size_t)r * S.pitch + 16 * min(q, nq - 1));
+            }
+            // (stores without a branch either: the optimiser sinks a load into the branch that holds its only use.  Lanes with
+            // nothing to store write the spare 16 bytes behind the window.)
+            const int spare = (srcPitch >> 4) * srcRows;
+#pragma unroll
+            for (int k = 0; k < NF; k++) w128[ok[k] ? tid + 256 * k : spare] = v[k];
+        } else {
+            for (int i = tid; i < nr * pq; i += 256) {
+                const int r = (int)(((float)i + 0.5f) * rcp_pq), q = i - r * pq;
+                if (q < nq) w128[i] = *reinterpret_cast<const uint4 *>(sp + (size_t)r * S.pitch + 16 * q);
+            }
         }
     }
     __syncthreads();
+    // The row taps must be in their registers in EVERY lane before lanes leave below: rows are read back with v_readlane
+    // from lanes 0..7, which a narrow last column block retires.  (Without this the optimiser sinks the load to its first
+    // use, behind the early return, and lanes 6 and 7 never load theirs.)
+    asm volatile("" ::"v"(ytap.x), "v"(ytap.y));
     const int dx4 = bx0 + (tid & 63) * 4;
     if (dx4 >= D.w) return;
     const uint4 t01 = *reinterpret_cast<const uint4 *>(tabs + D.xtab + dx4);       // 4 taps, 8 bytes each
@@ -1602,7 +1628,11 @@ void launch_pyramid(hipStream_t st, uint8_t *pyr, const Geom &g, const ResizeTap
     for (int l = 1; l < g.nlevels; l++) {
         dim3 grid((g.lv[l].w + 255) / 256, (g.lv[l].h + kResizeRows - 1) / kResizeRows, nimg);
         const int srcPitch = win[2 * l], srcRows = win[2 * l + 1];   // LDS window, sized on the host from the tables
-        hipLaunchKernelGGL(k_resize, grid, dim3(256), (size_t)srcPitch * srcRows, st, pyr, g, l, tabs, srcPitch, srcRows);
+        const int chunks = (srcPitch >> 4) * srcRows, nf = (chunks + 255) / 256;   // 16-byte loads per thread to fill the window
+        const size_t lds = (size_t)srcPitch * srcRows + 16;   // + the spare chunk idle fill lanes write
+        if (nf <= 4) hipLaunchKernelGGL(k_resize<4>, grid, dim3(256), lds, st, pyr, g, l, tabs, srcPitch, srcRows);
+        else if (nf <= 8) hipLaunchKernelGGL(k_resize<8>, grid, dim3(256), lds, st, pyr, g, l, tabs, srcPitch, srcRows);
+        else hipLaunchKernelGGL(k_resize<0>, grid, dim3(256), lds, st, pyr, g, l, tabs, srcPitch, srcRows);
     }
 }
 
