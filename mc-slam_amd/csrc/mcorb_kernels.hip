@@ -108,6 +108,11 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
         const int dy = min(wy0 + (l < kResizeRows / 4 ? l : 0), D.h - 1);
         ytap = *reinterpret_cast<const uint2 *>(tabs + D.ytab + dy);
     }
+    // the four column taps of this thread too (lanes past the row's end read the last group; they leave after the barrier)
+    const int dx4 = bx0 + (tid & 63) * 4;
+    const int dxc = min(dx4, ((D.w + 3) & ~3) - 4);
+    const uint4 t01 = *reinterpret_cast<const uint4 *>(tabs + D.xtab + dxc);       // 4 taps, 8 bytes each
+    const uint4 t23 = *reinterpret_cast<const uint4 *>(tabs + D.xtab + dxc + 2);
     {
         const uint8_t *sp = base + S.off + (size_t)sy0 * S.pitch + sx0;
         uint4 *w128 = reinterpret_cast<uint4 *>(win);
@@ -144,11 +149,8 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
     // The row taps must be in their registers in EVERY lane before lanes leave below: rows are read back with v_readlane
     // from lanes 0..7, which a narrow last column block retires.  (Without this the optimiser sinks the load to its first
     // use, behind the early return, and lanes 6 and 7 never load theirs.)
-    asm volatile("" ::"v"(ytap.x), "v"(ytap.y));
-    const int dx4 = bx0 + (tid & 63) * 4;
+    asm volatile("" ::"v"(ytap.x), "v"(ytap.y), "v"(t01.x), "v"(t01.y), "v"(t01.z), "v"(t01.w), "v"(t23.x), "v"(t23.y), "v"(t23.z), "v"(t23.w));
     if (dx4 >= D.w) return;
-    const uint4 t01 = *reinterpret_cast<const uint4 *>(tabs + D.xtab + dx4);       // 4 taps, 8 bytes each
-    const uint4 t23 = *reinterpret_cast<const uint4 *>(tabs + D.xtab + dx4 + 2);
     const uint32_t tw[8] = {t01.x, t01.y, t01.z, t01.w, t23.x, t23.y, t23.z, t23.w};
     // The table is padded to a multiple of four with copies of the row's last tap (build_resize_axis), so the taps of
     // columns past the image's edge are in range like any other; their pixels are masked out of the store.
