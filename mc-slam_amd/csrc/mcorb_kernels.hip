@@ -325,7 +325,7 @@ constexpr int kFastListCap = 768;
 #define EMIN __builtin_elementwise_min
 template <int TP>
 __device__ __forceinline__ int fast_pass1(const uint8_t *tile, const uint2 *cm, uint16_t *work, const FastCell &C, int T, int lane,
-                                          int &item0, int cap, const uint32_t *__restrict__ tab, int tabStride)
+                                          int &item0, int cap, const uint32_t *__restrict__ tab, int tabStride, uint32_t e_first)
 {
     const int items = C.hi * C.ng;
     // item = (row, group) in raster order, 64 consecutive items per trip.  Where an item lives in the LDS tile depends on
@@ -362,7 +362,7 @@ __device__ __forceinline__ int fast_pass1(const uint8_t *tile, const uint2 *cm, 
         nA += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
     };
     int i0 = item0;
-    uint32_t e = tb[0];                  // (the table is padded by 64 in-range entries past the last item)
+    uint32_t e = item0 == 0 ? e_first : tb[0];   // the first trip's entries were fetched with the ROI (the table is padded by 64 in-range entries past the last item)
     for (; i0 + 64 <= items && nA + 256 <= cap; i0 += 64) {   // full trips: every lane holds an item
         tb += 64;
         const uint32_t en = tb[0];       // next trip's entries travel while this one is tested
@@ -448,6 +448,9 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         return;
     }
 
+    // the first pass-1 trip's item entries travel together with the ROI (fetched inside pass 1 they were one more memory
+    // round trip at the head of every wave)
+    const uint32_t e_first = tab[(size_t)(C.ng * 2 + C.g0) * tabStride + lane];
     // ---- stage the ROI: row = lane, NQ 16-byte chunks per row (4-byte aligned in HBM, 16-byte aligned in LDS), all
     //      loads issued before the first LDS store; clear the score map, build the column masks ----
     for (int r = lane; r < C.rows; r += 64) {   // one trip unless the ROI is taller than 64 rows (70-px cells of odd resolutions)
@@ -468,6 +471,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
             cm[lane] = lane < NG ? uint2{a0 | a1, a2 | a3} : uint2{0, 0};
         }
     }
+    asm volatile("" ::"v"(e_first));   // keeps that load up here (the optimiser would sink it to its use)
     __syncthreads();   // single-wave workgroup: lowers to a wait, not an s_barrier
 
     uint32_t *dst = cell_kp + ((size_t)img * g.cells + C.cell) * g.cellCap;
@@ -514,7 +518,7 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 #pragma unroll 1
         for (;;) {
             const bool whole = item0 == 0;
-            const int nA = fast_pass1<TP>(tile, cm, work, C, T, lane, item0, cap, tab, tabStride);
+            const int nA = fast_pass1<TP>(tile, cm, work, C, T, lane, item0, cap, tab, tabStride, e_first);
             __syncthreads();
             if (sweep == 0) {
                 score(nA, T);
