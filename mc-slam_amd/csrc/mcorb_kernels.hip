@@ -17,6 +17,7 @@
 namespace mcorb {
 
 typedef short s16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // number of set bits of a wave mask below this lane, plus acc (v_mbcnt_lo/hi: two instructions)
@@ -205,13 +206,23 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
         const uint32_t b0 = yc & 0xffff, b1 = yc >> 16;   // row coefficients: 0 .. 2048
         // cv: (((b0 * H0) >> 16) + ((b1 * H1) >> 16) + 2) >> 2.  The +2 rides in the first product's upper half
         // (no carry can reach it from below), the two >> 16 are the upper halves of the products.
-        uint32_t v[4];
+        // T = upper half of p0 + upper half of p1 (<= 1023): the two >> 16 are the WORD_1 selectors of one SDWA add, which also
+        // drops every second result into the upper half of the previous pixel's register; >> 2 is then one packed shift per
+        // two pixels and the four bytes meet in one v_perm (15 instructions per four pixels; the compiler's own sequence of
+        // shifts, masks and ors took 30)
+        uint32_t p0[4], p1[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const uint32_t p0 = __umul24(b0, HA[k]) + 0x20000u, p1 = __umul24(b1, HB[k]);
-            v[k] = ((p0 >> 16) + (p1 >> 16)) >> 2;   // <= 255
+            p0[k] = __umul24(b0, HA[k]) + 0x20000u;
+            p1[k] = __umul24(b1, HB[k]);
         }
-        const uint32_t out = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+        uint32_t t01v, t23v;
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t01v) : "v"(p0[0]), "v"(p1[0]));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t01v) : "v"(p0[1]), "v"(p1[1]));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:WORD_1" : "=v"(t23v) : "v"(p0[2]), "v"(p1[2]));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1" : "+v"(t23v) : "v"(p0[3]), "v"(p1[3]));
+        const u16x2 s01 = __builtin_bit_cast(u16x2, t01v) >> (unsigned short)2, s23 = __builtin_bit_cast(u16x2, t23v) >> (unsigned short)2;
+        const uint32_t out = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, s23), __builtin_bit_cast(uint32_t, s01), 0x06040200u);
         *reinterpret_cast<uint32_t *>(base + D.off + (size_t)dy * D.pitch + dx4) = out & mask;
     }
 }
@@ -245,7 +256,6 @@ __global__ __launch_bounds__(256) void k_resize(uint8_t *__restrict__ pyr, Geom 
 //   pass 3  3x3 NMS over the work list (already in raster order = cv::FAST's output order),
 //           keypoints emitted straight to the cell's slot.
 // ---------------------------------------------------------------------------
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 struct FastCell {      // wave-uniform description of one cell
     int on;            // evaluated (not skipped by the reference's border rule, not degenerate)
