@@ -2,9 +2,9 @@
 //
 // Data flow of one batch (nimg equally sized images, all resident in HBM):
 //   phase A (GPU)  pyramid L1..L7 -> FAST score + cell NMS -> candidate compaction
-//                  (candidates land in host-mapped memory) ; blur queued behind it
-//   selection      host worker pool, one task per (image, level)        [mcorb_select.cpp]
-//   phase B (GPU)  BRIEF descriptors for the selected keypoints -> D2H
+//                  (bucket tables to the host by DMA; whole-level blur only in the IC-angle mode)
+//   selection      host worker pool, one task per image                 [mcorb_select.cpp]
+//   phase B (GPU)  blur around the selected keypoints + BRIEF descriptors (one kernel) -> D2H
 //   match (GPU)    all-pairs Hamming k-NN (k=2) + ratio/threshold flags -> host-mapped
 //   merge          per-frame IntraMatch track merge on the host
 // Each slot owns a stream, a complete buffer set and a driver thread, so several
@@ -786,7 +786,7 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
     launch_fast(s.st, s.d_pyr, geom, params.ini_th_fast, params.min_th_fast, d_fasttab, fast_tab_stride, fast_cell_off, s.d_cellkp, s.d_cellcnt, j.nimg);
     HIPCHK(hipEventRecord(s.ev[2], s.st));
     // compaction fills the per-image table blocks in device memory (a short kernel: it runs on the compute stream, ahead
-    // of the blur); the DMA that takes the blocks to the host runs on the side stream while the blur computes.
+    // of whatever comes next); the DMA that takes the blocks to the host runs on the side stream.
     static const bool side = getenv("MCORB_COMPACT_SIDE") != nullptr;   // round-1 placement, for comparison
     if (side) HIPCHK(hipStreamWaitEvent(s.st_copy, s.ev[2], 0));
     launch_compact(side ? s.st_copy : s.st, s.d_cellkp, s.d_cellcnt, geom, d_lut, s.d_sorted, s.h_cand, s.d_tbl, s.h_overflow, j.nimg);
