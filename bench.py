@@ -108,7 +108,7 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default="720p4")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; value = their median")
     ap.add_argument("--frames", type=int, default=None, help="rig frames per rank per step (default: slots x 128 images / cameras)")
-    ap.add_argument("--slots", type=int, default=None, help="buffer sets in flight per rank (default 6; 8 = 4 groups x 2 on the N>1 path)")
+    ap.add_argument("--slots", type=int, default=None, help="buffer sets in flight per rank (default 6; 12 = 6 groups x 2 on the N>1 path)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-frames", type=int, default=64, help="rig frames timed on the CPU oracle (one thread per camera)")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency leg (use when profiling kernels)")
@@ -160,7 +160,7 @@ def main():
                 os.dup2(saved, 1)
                 os.close(saved)
 
-    S = args.slots if args.slots else 6
+    S = args.slots if args.slots else (12 if DIST else 6)
     G = int(os.environ.get("MCORB_BENCH_GROUPS", "6")) if DIST else 1   # slot groups: with N > 1 G-1 groups extract ahead while one is matched
     IT = 2 if DIST else 1              # exchange rounds per step on the N > 1 path (one round = one group = SG slot jobs per rank)
     if DIST and S % G:
