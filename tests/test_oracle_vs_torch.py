@@ -47,3 +47,47 @@ def test_gaussian_blur_is_float_convolution_within_one_level(h, w):
     # tap, plus the final rounding
     assert d.max() < 1.5, d.max()
     assert np.mean(d < 0.75) > 0.95
+
+
+# cv::FAST (FAST-9/16 + cornerScore + 3x3 non-max suppression) against the textbook definition, written with whole-array
+# numpy operations -- no code or formula shared with the oracle's pixel loops.
+RING16 = [(0, 3), (1, 3), (2, 2), (3, 1), (3, 0), (3, -1), (2, -2), (1, -3), (0, -3), (-1, -3), (-2, -2), (-3, -1), (-3, 0), (-3, 1),
+          (-2, 2), (-1, 3)]
+
+
+def fast_by_definition(img, T):
+    img = img.astype(np.int32)
+    H, W = img.shape
+    v = img[3:H - 3, 3:W - 3]
+    ring = np.stack([img[3 + dy:H - 3 + dy, 3 + dx:W - 3 + dx] for dx, dy in RING16])
+    ext = np.concatenate([ring, ring[:8]])                                   # arcs wrap around
+    bright = np.max(np.stack([np.min(ext[s:s + 9] - v, axis=0) for s in range(16)]), axis=0)   # best arc's weakest margin
+    dark = np.max(np.stack([np.min(v - ext[s:s + 9], axis=0) for s in range(16)]), axis=0)
+    A = np.maximum(bright, dark)
+    corner = A > T                                                           # all nine strictly beyond v +- T
+    score = np.where(corner, A - 1, 0)                                       # largest t for which it still is one
+    full = np.zeros((H, W), np.int32)
+    full[3:H - 3, 3:W - 3] = score
+    return corner, score, full
+
+
+@pytest.mark.parametrize("T", [7, 20])
+def test_fast_is_the_segment_test_by_definition(T):
+    img = synth(90, 120, 5)
+    corner, score, full = fast_by_definition(img, T)
+    ys, xs = np.nonzero(corner)
+    want = sorted(zip((xs + 3).tolist(), (ys + 3).tolist(), score[ys, xs].tolist()), key=lambda t: (t[1], t[0]))
+    gx, gy, gs = O.fast(img, T, nonmax=False)
+    assert len(want) > 50
+    assert list(zip(gx.tolist(), gy.tolist())) == [(x, y) for x, y, _ in want]     # raster order; cv::FAST leaves the response 0 here
+    assert not gs.any()
+    # 3x3 non-max suppression: strictly above all eight neighbours (non-corners count as 0)
+    H, W = img.shape
+    keep = []
+    for x, y, s in want:
+        nb = full[y - 1:y + 2, x - 1:x + 2].copy()
+        nb[1, 1] = -1
+        if s > nb.max():
+            keep.append((x, y, s))
+    gx, gy, gs = O.fast(img, T, nonmax=True)
+    assert list(zip(gx.tolist(), gy.tolist(), gs.tolist())) == keep
