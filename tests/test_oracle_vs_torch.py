@@ -9,8 +9,14 @@ import pytest
 
 import oracle_lib as O
 
-torch = pytest.importorskip("torch")
-F = torch.nn.functional
+
+
+def _torch():
+    # imported inside the tests, not at collection: a `-m gpu` run collects this file too, and torch brings its own copy of
+    # the HIP runtime into the process, which the GPU tests that talk to libamdhip64 directly
+    # must not find loaded first
+    torch = pytest.importorskip("torch")
+    return torch, torch.nn.functional
 
 
 def synth(h, w, seed):
@@ -23,6 +29,7 @@ def synth(h, w, seed):
 @pytest.mark.parametrize("sw,sh,dw,dh", [(1280, 720, 1067, 600), (640, 480, 533, 400), (357, 201, 298, 168), (200, 150, 100, 75),
                                          (333, 217, 257, 181)])
 def test_resize_linear_is_torch_bilinear_within_one_level(sw, sh, dw, dh):
+    torch, F = _torch()
     img = synth(sh, sw, 3)
     got = O.resize_linear(img, dw, dh).astype(np.int32)
     ref = F.interpolate(torch.from_numpy(img.astype(np.float64))[None, None], size=(dh, dw), mode="bilinear", align_corners=False)[0, 0].numpy()
@@ -33,6 +40,7 @@ def test_resize_linear_is_torch_bilinear_within_one_level(sw, sh, dw, dh):
 
 @pytest.mark.parametrize("h,w", [(64, 80), (201, 357), (37, 53)])
 def test_gaussian_blur_is_float_convolution_within_one_level(h, w):
+    torch, F = _torch()
     img = synth(h, w, 11)
     got = O.gaussian_blur(img).astype(np.int32)
     x = np.arange(-3, 4, dtype=np.float64)
