@@ -309,17 +309,21 @@ static int copy_plane(mcorb_rig *r, int slot, int m, int level, bool blurred, ui
     HIPCHK(hipSetDevice(r->rig.device));
     HIPCHK(hipStreamSynchronize(s->st));
     const LevelGeom &L = g.lv[level];
-    const uint8_t *src = (blurred ? s->d_blur : s->d_pyr) + (size_t)m * g.imgBytes + L.off;
     if (!blurred) {
-        HIPCHK(hipMemcpy2D(dst, dst_stride, src, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy2D(dst, dst_stride, s->d_pyr + (size_t)m * g.imgBytes + L.off, L.pitch, L.w, L.h, hipMemcpyDeviceToHost));
         return MCORB_OK;
     }
-    if (!s->blur_valid) {   // reference mode never writes blurred planes (k_describe_fused): make them now from the slot's pyramid
+    if (!s->d_blur) {       // reference mode does not even allocate them (k_describe_fused blurs around the keypoints only)
+        HIPCHK(hipMalloc((void **)&s->d_blur, (size_t)r->rig.max_images * g.imgBytes));
+        HIPCHK(hipMemset(s->d_blur, 0, (size_t)r->rig.max_images * g.imgBytes));
+    }
+    if (!s->blur_valid) {   // ... nor writes them: make them now from the slot's pyramid
         launch_blur(s->st, s->d_pyr, s->d_blur, g, r->rig.max_images);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(s->st));
         s->blur_valid = true;
     }
+    const uint8_t *src = s->d_blur + (size_t)m * g.imgBytes + L.off;
     // blurred planes live in 16 x 8 tiles on the device (mcorb_common.h): fetch the tiled block, hand back rows
     const size_t rows = ((size_t)L.h + kBlurTileRows - 1) / kBlurTileRows * kBlurTileRows;
     std::vector<uint8_t> tmp(rows * L.pitch);

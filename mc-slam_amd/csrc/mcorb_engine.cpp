@@ -498,9 +498,11 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         }
         const size_t M = (size_t)max_images;
         TRY(dev_alloc(&s->d_pyr, M * geom.imgBytes));
-        TRY(dev_alloc(&s->d_blur, M * geom.imgBytes));
         HIPCHK(hipMemset(s->d_pyr, 0, M * geom.imgBytes));
-        HIPCHK(hipMemset(s->d_blur, 0, M * geom.imgBytes));
+        if (blur_planes) {   // whole blurred planes: only the plane-based descriptor paths write them with every job;
+            TRY(dev_alloc(&s->d_blur, M * geom.imgBytes));   // mcorb_rig_get_blurred allocates on first use otherwise
+            HIPCHK(hipMemset(s->d_blur, 0, M * geom.imgBytes));
+        }
         TRY(dev_alloc(&s->d_cellkp, M * geom.cells * geom.cellCap));
         TRY(dev_alloc(&s->d_cellcnt, M * geom.cells));
         TRY(dev_alloc(&s->d_sorted, M * geom.candCap));
