@@ -439,9 +439,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     HIPCHK(hipMemcpy(d_lut, lut.data(), lut.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     {
         std::vector<uint32_t> ft;
-        fast_tab_stride = fast_item_table(geom, ft);
-        while (ft.size() & 3) ft.push_back(0u);   // the cell records are read 16 bytes at a time
-        fast_cell_off = fast_cell_table(geom, ft);
+        fast_cell_off = fast_cell_table(geom, ft);   // (16-byte aligned: the records are read 16 bytes at a time)
         TRY(dev_alloc(&d_fasttab, ft.size()));
         HIPCHK(hipMemcpy(d_fasttab, ft.data(), ft.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
@@ -785,7 +783,7 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
     HIPCHK(hipEventRecord(s.ev[0], s.st));
     launch_pyramid(s.st, s.d_pyr, geom, d_taps, resize_win, j.nimg);
     HIPCHK(hipEventRecord(s.ev[1], s.st));
-    launch_fast(s.st, s.d_pyr, geom, params.ini_th_fast, params.min_th_fast, d_fasttab, fast_tab_stride, fast_cell_off, s.d_cellkp, s.d_cellcnt, j.nimg);
+    launch_fast(s.st, s.d_pyr, geom, params.ini_th_fast, params.min_th_fast, d_fasttab + fast_cell_off, s.d_cellkp, s.d_cellcnt, j.nimg);
     HIPCHK(hipEventRecord(s.ev[2], s.st));
     // compaction fills the per-image table blocks in device memory (a short kernel: it runs on the compute stream, ahead
     // of whatever comes next); the DMA that takes the blocks to the host runs on the side stream.

@@ -198,9 +198,8 @@ public:
     int device = 0;
     ResizeTap *d_taps = nullptr;
     uint16_t *d_lut = nullptr;             // path-code tables of all levels (k_compact)
-    uint32_t *d_fasttab = nullptr;         // k_fast_cells' item -> LDS offset table (fast_item_table)
-    int fast_tab_stride = 0;
-    int fast_cell_off = 0;                  // dword offset of the per-cell records inside d_fasttab (fast_cell_table)
+    uint32_t *d_fasttab = nullptr;         // k_fast_cells' per-cell records (fast_cell_table)
+    int fast_cell_off = 0;                  // dword offset of the records inside d_fasttab
     SelectParams selp[kMaxLevels];         // per-level DistributeOctTree constants + bucketing depth
     int resize_win[2 * kMaxLevels] = {};   // per level: LDS window pitch, rows (see launch_pyramid)
     std::vector<Slot *> slots;

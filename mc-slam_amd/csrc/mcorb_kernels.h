@@ -24,13 +24,10 @@ void launch_stage_f32(hipStream_t st, const float *src, int w, int h, int pitch_
                       uint8_t *pyr, const Geom &g, int nimg);
 // win[2*l], win[2*l+1]: LDS source-window pitch (bytes, multiple of 4) and rows of level l's resize workgroups
 void launch_pyramid(hipStream_t st, uint8_t *pyr, const Geom &g, const ResizeTap *tabs, const int *win, int nimg);
-constexpr int kFastMaxGroups = 24;   // 4-px groups of an LDS tile row (pitch <= 96)
-// k_fast_cells' item table for this geometry (built once per rig, uploaded by the caller): for every (groups per row ng,
-// first group g0) the LDS byte offset | group << 16 of item i = (row i / ng, group i % ng); returns the row stride of the
-// table (entries per (ng, g0))
-int fast_item_table(const Geom &g, std::vector<uint32_t> &tab);
-int fast_cell_table(const Geom &g, std::vector<uint32_t> &tab);   // appends the per-cell records, returns their dword offset
-void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, const uint32_t *tab, int tabStride, int cellRecOff,
+// k_fast_cells' per-cell records for this geometry (built once per rig, uploaded by the caller): ROI origin, size,
+// pass-1 lane layout; appended to `tab`, returns their dword offset
+int fast_cell_table(const Geom &g, std::vector<uint32_t> &tab);
+void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, const uint32_t *cellRec,
                  uint32_t *cell_kp, int *cell_cnt, int nimg);
 // tbl: device table blocks (tbl_ints(g.bucketTotal) ints per image, layout in mcorb_common.h); cand / overflow: host-mapped
 // lut: path-code tables (LevelGeom::lutx / luty)

@@ -12,6 +12,7 @@
 #include "mcorb_common.h"
 #include "mcorb_kernels.h"
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 namespace mcorb {
@@ -264,19 +265,22 @@ struct FastCell {      // wave-uniform description of one cell
     int wi, hi;        // evaluated columns / rows (ROI minus FAST's 3-px margin)
     int rows;          // ROI rows
     int g0, ng;        // first 4-px group holding an evaluated column, number of such groups
+    int R;             // rows one pass-1 trip covers: 64 / ng
+    float rcp_ng;      // 1 / ng
+    uint32_t headMask, tailMask;   // pass-bit masks (FastLane::vmask's positions) of the evaluated columns of a row's first / last group
     uint32_t org;      // pack_cand(cj*wCell - ph, ci*hCell, 0) mod 2^32: tile (col, row) -> candidate record
     const uint8_t *src;   // first staged byte (ROI row 0, column iniX - ph)
     int pitch;         // HBM row pitch of the level
 };
 
-// The cell's record comes from a host-built table (fast_cell_table(), 8 dwords per cell of an image, behind the item
-// tables): one scalar load instead of a seven-step search for the cell's level, a division and ~40 scalar instructions of
-// ROI arithmetic at the head of each of the 254 k waves of a launch.
+// The cell's record comes from a host-built table (fast_cell_table(), 8 dwords per cell of an image): one scalar load
+// instead of a seven-step search for the cell's level, a division and ~40 scalar instructions of ROI arithmetic at the
+// head of each of the 254 k waves of a launch.
 constexpr int kFastCellRecDw = 8;
 __device__ __forceinline__ void fast_cell_setup(const uint8_t *pyr, const Geom &g, int img, int cell, const uint32_t *__restrict__ rec, FastCell &C)
 {
     const uint4 r = *reinterpret_cast<const uint4 *>(rec + (size_t)cell * kFastCellRecDw);
-    const uint32_t r4 = rec[(size_t)cell * kFastCellRecDw + 4];
+    const uint2 r4 = *reinterpret_cast<const uint2 *>(rec + (size_t)cell * kFastCellRecDw + 4);
     C.cell = cell;
     C.src = pyr + (size_t)img * g.imgBytes + r.x;
     C.org = r.y;
@@ -286,8 +290,13 @@ __device__ __forceinline__ void fast_cell_setup(const uint8_t *pyr, const Geom &
     C.hi = (int)((r.w >> 16) & 0xff);
     C.on = (int)((r.w >> 24) & 1);
     C.ph = (int)((r.w >> 25) & 3);
-    C.g0 = (int)(r4 & 0xff);
-    C.ng = (int)(r4 >> 8);
+    C.g0 = (int)(r4.x & 0xff);
+    C.ng = (int)((r4.x >> 8) & 0xff);
+    C.R = (int)(r4.x >> 16);
+    C.rcp_ng = __uint_as_float(r4.y);
+    const uint2 r6 = *reinterpret_cast<const uint2 *>(rec + (size_t)cell * kFastCellRecDw + 6);
+    C.headMask = r6.x;
+    C.tailMask = r6.y;
 }
 
 // host: the records, exactly the reference's ROI arithmetic (ORBextractor.cpp:804-833; float there, exact in int)
@@ -316,74 +325,149 @@ int fast_cell_table(const Geom &g, std::vector<uint32_t> &tab)
             r[1] = ((uint32_t)(ci * L.hCell) << 20) + ((uint32_t)(cj * L.wCell - ph) << 8);
             r[2] = (uint32_t)L.pitch;
             r[3] = on ? ((uint32_t)rows | ((uint32_t)wi << 8) | ((uint32_t)hi << 16) | (1u << 24) | ((uint32_t)ph << 25)) : 0u;
-            r[4] = (uint32_t)g0 | ((uint32_t)ng << 8);
+            r[4] = (uint32_t)g0 | ((uint32_t)ng << 8) | ((uint32_t)(64 / ng) << 16);
+            const float rcp = 1.0f / (float)ng;
+            uint32_t bits;
+            memcpy(&bits, &rcp, 4);
+            r[5] = bits;
+            // evaluated tile columns: [ph + 3, ph + 3 + wi); only a row's first and last group can hold columns outside
+            auto pxmask = [&](int G) {
+                static const uint32_t bit[4] = {1u << 15, 1u, 1u << 31, 1u << 16};   // px0, px1, px2, px3
+                uint32_t m = 0;
+                for (int j = 0; j < 4; j++) {
+                    const int x = 4 * G + j - (ph + 3);
+                    if (x >= 0 && x < wi) m |= bit[j];
+                }
+                return m;
+            };
+            r[6] = on ? pxmask(g0) : 0u;
+            r[7] = on ? pxmask(g0 + ng - 1) : 0u;
         }
     }
     return off;
 }
 
-// Work-list capacity.  A trip of pass 1 appends at most 256 entries and runs only while 256 more still fit, so the
-// list never overflows; a cell with more survivors than that (dense texture, noise) is processed in several chunks
-// (see the kernel).  The capacity also sets the wave's LDS footprint and with it the occupancy; measured at 720p
-// (128 images): 512 entries = 5.0 KiB = 32 waves per CU: 410 us; 640: 387; 768 = 5.5 KiB = 29 waves: 380; 832: 377;
-// 896: 403; 1024 = 26 waves: 402.  The benchmark's cells hold 80 survivors on average, 250 at most.
+// Work-list capacity (pixels).  Pass 1 appends one entry per surviving 4-px GROUP (at most 64 per trip) and runs only while
+// 64 more still fit cap / 4 groups, so the pixel list the groups expand into never overflows; a cell with more survivors
+// than that (dense texture, noise) is processed in several chunks (see the kernel).  The capacity also sets the wave's
+// LDS footprint and with it the occupancy; measured at 720p (128 images) with the round-2 kernel: 512 entries = 32 waves
+// per CU: 410 us; 640: 387; 768 = 29 waves: 380; 832: 377; 896: 403; 1024 = 26 waves: 402.  The benchmark's cells hold 80
+// survivors on average, 250 at most.
 constexpr int kFastListCap = 768;
 
-// pass 1 over one cell, from item `item0` (a multiple of 64) until the cell is done or the list is full; returns the
-// length of the work list and advances item0
 #define EMAX __builtin_elementwise_max
 #define EMIN __builtin_elementwise_min
+// Per-lane constants of pass 1 for one cell.  A trip covers R = 64 / ng consecutive rows of the cell: lane = r * ng + gi
+// tests the 4-px group gi of row (trip's first row + r), which is the raster order of the groups.  Nothing about a lane's
+// place changes from trip to trip except the row base, so the tile offset, the column-validity mask and the entry code
+// are computed once per cell (round 2 looked them up per trip in a host-built item table: a global load, an LDS read
+// and six vector instructions per trip).
+struct FastLane {
+    int off0;          // tile byte offset of the lane's group in the cell's first row (inactive lanes: a valid one)
+    uint32_t vmask;    // pass bits of the group's evaluated columns: px0 -> bit 15, px1 -> bit 0, px2 -> bit 31, px3 -> bit 16
+};
 template <int TP>
-__device__ __forceinline__ int fast_pass1(const uint8_t *tile, const uint2 *cm, uint16_t *work, const FastCell &C, int T, int lane,
-                                          int &item0, int cap, const uint32_t *__restrict__ tab, int tabStride, uint32_t e_first)
+__device__ __forceinline__ FastLane fast_lane_setup(const FastCell &C, int lane)
 {
-    const int items = C.hi * C.ng;
-    // item = (row, group) in raster order, 64 consecutive items per trip.  Where an item lives in the LDS tile depends on
-    // (groups per row, first group) only: the host tabulated it (fast_item_table(): entry = tile byte offset | group << 16),
-    // so a trip costs one coalesced 256-byte load instead of a divide-free but 10-instruction index update per lane.
-    const uint32_t *tb = tab + (size_t)(C.ng * 2 + C.g0) * tabStride + item0 + lane;
-    int nA = 0;
-    auto trip = [&](uint32_t e, bool in) {
-        const int off = in ? (int)(e & 0xffffu) : 3 * TP;   // tile byte = work-list entry
-        const int G = in ? (int)(e >> 16) : TP / 4;          // column-mask entry; TP/4 is the all-zero one
+    FastLane L;
+    const int r = (int)(((float)lane + 0.5f) * C.rcp_ng);   // lane / ng (the product is at least 1 / (2 ng) away from an integer)
+    const int gi = lane - r * C.ng;
+    const bool act = r < C.R;
+    L.off0 = act ? (3 + r) * TP + 4 * (C.g0 + gi) : 3 * TP + 4 * C.g0;
+    uint32_t m = 0x80018001u;
+    m = gi == 0 ? m & C.headMask : m;
+    m = gi == C.ng - 1 ? m & C.tailMask : m;
+    L.vmask = act ? m : 0u;
+    return L;
+}
+
+// pass 1 over one cell, from row `row0` (a multiple of R) until the cell is done or the group list is full; returns the
+// number of group entries and advances row0.  Entry = pass bits (FastLane::vmask's positions) | tile byte offset >> 1.
+//
+// The necessary condition is evaluated WITHOUT unpacking bytes to 16 bits for half of the pixels: the packed u16
+// min / max of two raw dwords orders the lanes by their HIGH byte first, so its high byte is the min / max of the high
+// bytes whatever the low bytes hold.  The odd pixels of a group (bytes 1, 3) therefore run on the raw dwords, on values
+// scaled by 256 with garbage below, masked once before the two subtractions (v_and: a 2-cycle instruction; the ten
+// v_perm of the round-2 version were 4-cycle ones); the even pixels (bytes 0, 2) on the dwords masked with 0x00ff00ff.
+//   odd:   w = max(sat(hi - V), sat(V - lo)) in units of 256;  pass <=> w >= 256 (T + 1) <=> sat(w - (256 T + 255)) is odd
+//   even:  w = max(hi - V, V - lo);                            pass <=> T - w < 0 (sign bit)
+template <int TP>
+__device__ __forceinline__ int fast_pass1(const uint8_t *tile, uint32_t *glist, const FastCell &C, int T, int lane, int &row0, int gcap,
+                                          const FastLane &L)
+{
+    const u16x2 Tev = u16x2{(unsigned short)T, (unsigned short)T};
+    const u16x2 Tod = u16x2{(unsigned short)(256 * T + 255), (unsigned short)(256 * T + 255)};
+    int nG = 0;
+    auto trip = [&](int rb, bool tail) {
+        int off = L.off0 + rb * TP;
+        bool in = true;
+        if (tail) {   // last trip: rows past the cell's end read a valid row and are masked out of the ballot
+            in = (int)(((float)lane + 0.5f) * C.rcp_ng) + rb < C.hi;
+            off = in ? off : 3 * TP + 4 * C.g0;
+        }
         const uint32_t *p = reinterpret_cast<const uint32_t *>(tile + off);
-        const uint2 vm = cm[G];   // 0xffff per evaluated column of the group
         const uint32_t Cc = p[0], Cl = p[-1], Cr = p[1], Up = p[-3 * (TP / 4)], Dn = p[3 * (TP / 4)];
         const uint32_t Lf = __builtin_amdgcn_alignbyte(Cc, Cl, 1);   // px 4G-3 .. 4G
         const uint32_t Rt = __builtin_amdgcn_alignbyte(Cr, Cc, 3);   // px 4G+3 .. 4G+6
-#define LO2(X) __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, X, 0x0c010c00u))
-#define HI2(X) __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, X, 0x0c030c02u))
-        const s16x2 V0 = LO2(Cc), V1 = HI2(Cc), U0 = LO2(Up), U1 = HI2(Up), D0 = LO2(Dn), D1 = HI2(Dn);
-        const s16x2 L0 = LO2(Lf), L1 = HI2(Lf), R0 = LO2(Rt), R1 = HI2(Rt);
-#undef LO2
-#undef HI2
-        const s16x2 w0 = EMAX(EMIN(EMAX(U0, D0), EMAX(L0, R0)) - V0, V0 - EMAX(EMIN(U0, D0), EMIN(L0, R0)));
-        const s16x2 w1 = EMAX(EMIN(EMAX(U1, D1), EMAX(L1, R1)) - V1, V1 - EMAX(EMIN(U1, D1), EMIN(L1, R1)));
-        const s16x2 m0 = __builtin_bit_cast(s16x2, __builtin_bit_cast(uint32_t, w0) & vm.x);
-        const s16x2 m1 = __builtin_bit_cast(s16x2, __builtin_bit_cast(uint32_t, w1) & vm.y);
-        const bool c0 = m0.x > T, c1 = m0.y > T, c2 = m1.x > T, c3 = m1.y > T;   // T >= 0: masked-out columns never pass
-        const unsigned long long b0 = __builtin_amdgcn_ballot_w64(c0), b1 = __builtin_amdgcn_ballot_w64(c1),
-                                 b2 = __builtin_amdgcn_ballot_w64(c2), b3 = __builtin_amdgcn_ballot_w64(c3);
-        int o = lane_rank(b3, lane_rank(b2, lane_rank(b1, lane_rank(b0, nA))));
-        if (c0) work[o++] = (uint16_t)off;
-        if (c1) work[o++] = (uint16_t)(off + 1);
-        if (c2) work[o++] = (uint16_t)(off + 2);
-        if (c3) work[o++] = (uint16_t)(off + 3);
-        nA += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
+#define U16(X) __builtin_bit_cast(u16x2, (uint32_t)(X))
+#define S16(X) __builtin_bit_cast(s16x2, (uint32_t)(X))
+        // odd pixels: high bytes, raw
+        const u16x2 hO = EMIN(EMAX(U16(Up), U16(Dn)), EMAX(U16(Lf), U16(Rt)));
+        const u16x2 lO = EMAX(EMIN(U16(Up), U16(Dn)), EMIN(U16(Lf), U16(Rt)));
+        const u16x2 hOm = U16(__builtin_bit_cast(uint32_t, hO) & 0xff00ff00u), lOm = U16(__builtin_bit_cast(uint32_t, lO) & 0xff00ff00u);
+        const u16x2 vO = U16(Cc & 0xff00ff00u);
+        const u16x2 wO = EMAX(__builtin_elementwise_sub_sat(hOm, vO), __builtin_elementwise_sub_sat(vO, lOm));
+        const uint32_t zO = __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(wO, Tod));   // bit 0 / 16 set <=> px1 / px3 pass
+        // even pixels: low bytes
+        const s16x2 vE = S16(Cc & 0x00ff00ffu), uE = S16(Up & 0x00ff00ffu), dE = S16(Dn & 0x00ff00ffu);
+        const s16x2 lE = S16(Lf & 0x00ff00ffu), rE = S16(Rt & 0x00ff00ffu);
+        const s16x2 wE = EMAX(EMIN(EMAX(uE, dE), EMAX(lE, rE)) - vE, vE - EMAX(EMIN(uE, dE), EMIN(lE, rE)));
+        const uint32_t sE = __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, Tev) - wE);           // bit 15 / 31 set <=> px0 / px2 pass
+#undef U16
+#undef S16
+        const uint32_t M = ((sE & 0x80008000u) | (zO & 0x00010001u)) & L.vmask;
+        const bool c = M != 0 && in;
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(c);
+        if (c) glist[lane_rank(b, nG)] = M | ((uint32_t)off >> 1);
+        nG += __popcll(b);
     };
-    int i0 = item0;
-    uint32_t e = item0 == 0 ? e_first : tb[0];   // the first trip's entries were fetched with the ROI (the table is padded by 64 in-range entries past the last item)
-    for (; i0 + 64 <= items && nA + 256 <= cap; i0 += 64) {   // full trips: every lane holds an item
-        tb += 64;
-        const uint32_t en = tb[0];       // next trip's entries travel while this one is tested
-        trip(e, true);
-        e = en;
+    int rb = row0;
+    for (; rb + C.R <= C.hi && nG + 64 <= gcap; rb += C.R) trip(rb, false);   // full trips: every active lane holds a row of the cell
+    if (rb < C.hi && rb + C.R > C.hi && nG + 64 <= gcap) {
+        trip(rb, true);
+        rb += C.R;
     }
-    if (i0 < items && i0 + 64 > items && nA + 256 <= cap) {   // last trip: lanes past the end take the all-zero mask entry
-        trip(e, i0 + lane < items);   // (a select, not a branch: the ballots inside need the whole wave)
-        i0 += 64;
+    row0 = rb;
+    return nG;
+}
+
+// group entries -> pixel work list (tile byte offsets, raster order: groups are in raster order, pixels ascend inside a
+// group).  64 groups per trip; a group holds 1 .. 4 survivors: lane's first slot = groups before it + their extra
+// survivors (two ballots over the bits of n - 1).  The group list sits in the tail of the pixel list's buffer (see the
+// kernel): all of a trip's entries are in registers before its first pixel is written, and 4 (g + 64) <= cap pixels
+// written after g + 64 groups never reach entry g + 64.
+__device__ __forceinline__ int fast_expand(const uint32_t *glist, uint16_t *work, int nG, int lane)
+{
+    int nA = 0;
+    for (int i0 = 0; i0 < nG; i0 += 64) {
+        const bool in = i0 + lane < nG;
+        const uint32_t E = in ? glist[i0 + lane] : 0u;
+        const uint32_t m = E & 0x80018001u;
+        const int n1 = in ? __popc(m) - 1 : 0;   // survivors of the group beyond the first
+        const unsigned long long b0 = __builtin_amdgcn_ballot_w64((n1 & 1) != 0), b1 = __builtin_amdgcn_ballot_w64(n1 >= 2);
+        int o = nA + lane + lane_rank(b0) + 2 * lane_rank(b1);
+        const uint32_t off = (E & 0x3ffeu) << 1;
+        // the list entries are read before the pixel slots that overlay them are written: same wave, LDS executes a wave's
+        // accesses in program order -- the compiler must keep that order too (the two pointers differ in type)
+        asm volatile("" ::: "memory");
+        if (m & 0x8000u) work[o++] = (uint16_t)off;
+        if (m & 0x1u) work[o++] = (uint16_t)(off + 1);
+        if (m & 0x80000000u) work[o++] = (uint16_t)(off + 2);
+        if (m & 0x10000u) work[o++] = (uint16_t)(off + 3);
+        const int cnt = min(nG - i0, 64);
+        nA += cnt + __popcll(b0) + 2 * __popcll(b1);
+        asm volatile("" ::: "memory");
     }
-    item0 = i0;
     return nA;
 }
 
@@ -391,9 +475,14 @@ __device__ __forceinline__ int fast_pass1(const uint8_t *tile, const uint2 *cm, 
 // (Fetching the ring with seven unaligned ds_read_b32/b64 per pixel instead of 17 byte reads is functionally fine on
 // gfx950 but was measured 2x slower for the whole kernel: 900 vs 435 us per 128 images.)
 template <int TP>
-__device__ __forceinline__ int fast_arc_score(const uint8_t *lo)   // lo = &pixel[-3 rows][-3 columns]: all offsets >= 0
+__device__ __forceinline__ int fast_arc_score(const uint8_t *tile, int pos)   // pos = tile byte offset of the pixel
 {
-    const uint8_t *c = lo + 3 * TP + 3;
+    // (the base offset &pixel[-3 rows][-3 columns] is pinned in its register: left alone the compiler rebases on the centre
+    // pixel and spends seven vector adds per survivor on the ring bytes whose offsets are then negative -- ds_read
+    // offsets are unsigned)
+    int lo = pos - (3 * TP + 3);
+    asm volatile("" : "+v"(lo));
+    const uint8_t *c = tile + lo + (3 * TP + 3);
     // ring offsets (dx,dy), k = 0..15 (cv::FAST makeOffsets, patternSize 16): (0,3),(1,3),(2,2),(3,1),(3,0),(3,-1),(2,-2),(1,-3),
     // then the same negated for k+8.  X[k] = (r[k], r[k+8]) as two u16
     u16x2 X[8];
@@ -432,37 +521,36 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *lo)   // lo = &pixe
 // One wave per cell.  (Several cells per wave, one after the other with the next ROI prefetched into registers, or two
 // cells with pooled survivor lists, were measured slower: the extra LDS / SGPRs cost more occupancy than they save --
 // 443-456 us and 787 us against 431 us per 128 images.)
-// LDS of the wave: [16 B][tile, tileB][16 B][score map of ROI rows 2 .. rows-3, scB][16 B][column masks, (TP/4 + 1) x 8 B]
-// [work list, cap x 2 B] = 5.5 KiB at TP = 48: 29 waves per CU (the measured optimum); <= 80 SGPRs and <= 64 VGPRs leave 8 waves per SIMD.
+// LDS of the wave: [16 B][tile, tileB][16 B][score map of ROI rows 2 .. rows-3, scB][16 B][work list, cap x 2 B; its second
+// half doubles as the group list of pass 1] = 5.4 KiB at TP = 48; <= 80 SGPRs and <= 64 VGPRs leave 8 waves per SIMD.
 template <int TP>
 __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ pyr, Geom g, int iniTh, int minTh,
-                                                   int tileB, int scB, int cap, const uint32_t *__restrict__ tab, int tabStride, int cellRecOff,
+                                                   int tileB, int scB, int cap, const uint32_t *__restrict__ cellRec,
                                                    uint32_t *__restrict__ cell_kp, int *__restrict__ cell_cnt)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    constexpr int NQ = TP / 16, NG = TP / 4;
+    constexpr int NQ = TP / 16;
     uint8_t *tile = lds + 16;
     uint8_t *sc = tile + tileB + 16;          // score of tile byte `pos` lives at sc2[pos]: NMS touches rows 2 .. rows-3 only
     uint8_t *sc2 = sc - 2 * TP;
-    uint2 *cm = reinterpret_cast<uint2 *>(sc + scB + 16);
-    uint16_t *work = reinterpret_cast<uint16_t *>(cm + (NG + 1));
+    uint16_t *work = reinterpret_cast<uint16_t *>(sc + scB + 16);
+    uint32_t *glist = reinterpret_cast<uint32_t *>(work + cap / 2);   // cap / 4 group entries in the list's second half
+    const int gcap = cap >> 2;
     struct __attribute__((packed, aligned(4))) Chunk { uint32_t a, b, c, d; };
 
     const int lane = threadIdx.x;
     const int img = blockIdx.y;
     FastCell C;
-    fast_cell_setup(pyr, g, img, __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x)), tab + cellRecOff, C);
+    fast_cell_setup(pyr, g, img, __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x)), cellRec, C);
     int *out_cnt = cell_cnt + (size_t)img * g.cells + C.cell;
     if (!C.on) {
         if (lane == 0) *out_cnt = 0;
         return;
     }
 
-    // the first pass-1 trip's item entries travel together with the ROI (fetched inside pass 1 they were one more memory
-    // round trip at the head of every wave)
-    const uint32_t e_first = tab[(size_t)(C.ng * 2 + C.g0) * tabStride + lane];
     // ---- stage the ROI: row = lane, NQ 16-byte chunks per row (4-byte aligned in HBM, 16-byte aligned in LDS), all
-    //      loads issued before the first LDS store; clear the score map, build the column masks ----
+    //      loads issued before the first LDS store; clear the score map; the lane's pass-1 constants meanwhile ----
+    FastLane FL;
     for (int r = lane; r < C.rows; r += 64) {   // one trip unless the ROI is taller than 64 rows (70-px cells of odd resolutions)
         Chunk ch[NQ];
 #pragma unroll
@@ -474,24 +562,17 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     {
         uint4 *s128 = reinterpret_cast<uint4 *>(sc);
         for (int i = lane; i < scB / 16; i += 64) s128[i] = uint4{0, 0, 0, 0};
-        if (lane <= NG) {   // evaluated tile columns of this cell: [ph + 3, ph + 3 + wi); entry NG stays all-zero
-            const int x = 4 * lane - (C.ph + 3);
-            const uint32_t a0 = (unsigned)x < (unsigned)C.wi ? 0xffffu : 0u, a1 = (unsigned)(x + 1) < (unsigned)C.wi ? 0xffff0000u : 0u;
-            const uint32_t a2 = (unsigned)(x + 2) < (unsigned)C.wi ? 0xffffu : 0u, a3 = (unsigned)(x + 3) < (unsigned)C.wi ? 0xffff0000u : 0u;
-            cm[lane] = lane < NG ? uint2{a0 | a1, a2 | a3} : uint2{0, 0};
-        }
+        FL = fast_lane_setup<TP>(C, lane);
     }
-    asm volatile("" ::"v"(e_first));   // keeps that load up here (the optimiser would sink it to its use)
     __syncthreads();   // single-wave workgroup: lowers to a wait, not an s_barrier
 
     uint32_t *dst = cell_kp + ((size_t)img * g.cells + C.cell) * g.cellCap;
-    const int items = C.hi * C.ng;
     int total = 0;
     // pass 2: full arc score of the survivors; the score map gets A where A > T, 0 elsewhere
     auto score = [&](int nA, int T) {
         for (int i = lane; i < nA; i += 64) {
             const int pos = work[i];
-            const int a = fast_arc_score<TP>(tile + (pos - 3 * TP - 3));
+            const int a = fast_arc_score<TP>(tile, pos);
             sc2[pos] = (uint8_t)(a > T ? a : 0);
         }
     };
@@ -500,16 +581,20 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
     auto nms = [&](int nA) {
         for (int i0 = 0; i0 < nA; i0 += 64) {
             const int i = i0 + lane;
-            const int pos = work[i < nA ? i : nA - 1];
-            const uint8_t *s = sc2 + pos;
+            // lanes past the list's end look at tile byte 3 * TP: column 0 is never evaluated, its score stays 0, and a
+            // zero score is never strictly above its neighbours'
+            const int pos = i < nA ? (int)work[i] : 3 * TP;
+            int lo = pos - (TP + 1);   // &score[-1 row][-1 column], pinned so that all nine offsets are non-negative immediates
+            asm volatile("" : "+v"(lo));
+            const uint8_t *s = sc2 + lo + (TP + 1);
             const uint32_t a = s[0];
             const uint32_t n = max(max(max((uint32_t)s[1], (uint32_t)s[-1]), max((uint32_t)s[-TP - 1], (uint32_t)s[-TP])),
                                    max(max((uint32_t)s[-TP + 1], (uint32_t)s[TP - 1]), max((uint32_t)s[TP], (uint32_t)s[TP + 1])));
-            const bool keep = i < nA && a > n;
+            const bool keep = a > n;
             const unsigned long long b = __builtin_amdgcn_ballot_w64(keep);
             if (keep) {
                 const int o = lane_rank(b, total);
-                const int yy = (int)(((float)pos + 0.5f) * (1.0f / (float)TP)), xx = pos - yy * TP;   // tile coordinates
+                const int yy = (int)(((float)pos + 0.5f) * (1.0f / (float)TP)), xx = __mul24(yy, -TP) + pos;   // tile coordinates
                 // keypoint coordinates relative to minBorder: FAST's ROI coordinate + cell origin (:864-865)
                 if (o < g.cellCap) dst[o] = C.org + ((uint32_t)yy << 20) + ((uint32_t)xx << 8) + (a - 1);
             }
@@ -524,21 +609,23 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
         // sweep 0 scores the survivors, chunk by chunk when the list cannot hold them all; the usual cell fits in
         // one chunk and is finished right away.  Otherwise sweep 1 goes over the cell again for the NMS (the
         // score map is complete by then).
-        int item0 = 0, sweep = 0;
+        int row0 = 0, sweep = 0;
 #pragma unroll 1
         for (;;) {
-            const bool whole = item0 == 0;
-            const int nA = fast_pass1<TP>(tile, cm, work, C, T, lane, item0, cap, tab, tabStride, e_first);
+            const bool whole = row0 == 0;
+            const int nG = fast_pass1<TP>(tile, glist, C, T, lane, row0, gcap, FL);
+            __syncthreads();
+            const int nA = fast_expand(glist, work, nG, lane);
             __syncthreads();
             if (sweep == 0) {
                 score(nA, T);
                 __syncthreads();
             }
-            if (sweep == 1 || (whole && item0 >= items)) nms(nA);
-            if (item0 >= items) {
+            if (sweep == 1 || (whole && row0 >= C.hi)) nms(nA);
+            if (row0 >= C.hi) {
                 if (sweep == 1 || whole) break;
                 sweep = 1;
-                item0 = 0;
+                row0 = 0;
             }
             __syncthreads();
         }
@@ -1665,42 +1752,24 @@ void fast_layout(const Geom &g, int &tp, int &rows)
     tp = pitch <= 48 ? 48 : (pitch <= 64 ? 64 : 80);   // wCell < 70 by construction (build_geometry): pitch <= 80
 }
 
-int fast_item_table(const Geom &g, std::vector<uint32_t> &tab)
-{
-    int tp, rows;
-    fast_layout(g, tp, rows);
-    const int hiMax = rows - 6, stride = hiMax * kFastMaxGroups + 64;
-    tab.assign((size_t)(kFastMaxGroups + 1) * 2 * stride, 0u);
-    for (int ng = 1; ng <= kFastMaxGroups; ng++)
-        for (int g0 = 0; g0 < 2; g0++) {
-            uint32_t *t = tab.data() + (size_t)(ng * 2 + g0) * stride;
-            for (int i = 0; i < stride; i++) {
-                int r = i / ng;
-                const int gi = i - r * ng;
-                if (r > hiMax - 1) r = hiMax - 1;   // padding past the last item: any in-range address
-                const int G = g0 + gi < tp / 4 ? g0 + gi : tp / 4 - 1;
-                t[i] = (uint32_t)((r + 3) * tp + 4 * G) | ((uint32_t)G << 16);
-            }
-        }
-    return stride;
-}
-
-void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, const uint32_t *tab, int tabStride, int cellRecOff,
+void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, int minTh, const uint32_t *cellRec,
                  uint32_t *cell_kp, int *cell_cnt, int nimg)
 {
-    // LDS per wave: the tile, the score map (four rows fewer), the column masks, the bounded survivor list
+    // LDS per wave: the tile, the score map (four rows fewer), the bounded survivor list
     int tp, rows;
     fast_layout(g, tp, rows);
-    static const int cap_env = getenv("MCORB_FAST_LISTCAP") ? atoi(getenv("MCORB_FAST_LISTCAP")) : 0;   // tuning knob; any value >= 512 is safe
-    const int cap = cap_env >= 512 ? cap_env : kFastListCap;
+    static const int cap_env = getenv("MCORB_FAST_LISTCAP") ? atoi(getenv("MCORB_FAST_LISTCAP")) : 0;   // tuning knob; any multiple of 8 >= 512 is safe
+    const int cap = cap_env >= 512 ? (cap_env & ~7) : kFastListCap;
     const int tileB = (rows * tp + 15) & ~15, scB = ((rows - 4) * tp + 15) & ~15;
-    const size_t lds = 16 + (size_t)tileB + 16 + (size_t)scB + 16 + (size_t)(tp / 4 + 1) * 8 + (size_t)cap * 2;
+    const size_t lds = 16 + (size_t)tileB + 16 + (size_t)scB + 16 + (size_t)cap * 2;
     dim3 grid(g.cells, nimg);
-    if (iniTh < 0) iniTh = 0;   // (the kernel's column masks rely on thresholds >= 0; FAST thresholds are)
+    if (iniTh < 0) iniTh = 0;   // (pass 1's sign tests rely on thresholds in 0 .. 255; FAST thresholds are)
     if (minTh < 0) minTh = 0;
-    if (tp == 48) hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, tab, tabStride, cellRecOff, cell_kp, cell_cnt);
-    else if (tp == 64) hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, tab, tabStride, cellRecOff, cell_kp, cell_cnt);
-    else hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, tab, tabStride, cellRecOff, cell_kp, cell_cnt);
+    if (iniTh > 255) iniTh = 255;   // no pixel passes at 255 or above either way
+    if (minTh > 255) minTh = 255;
+    if (tp == 48) hipLaunchKernelGGL(k_fast_cells<48>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, cellRec, cell_kp, cell_cnt);
+    else if (tp == 64) hipLaunchKernelGGL(k_fast_cells<64>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, cellRec, cell_kp, cell_cnt);
+    else hipLaunchKernelGGL(k_fast_cells<80>, grid, dim3(64), lds, st, pyr, g, iniTh, minTh, tileB, scB, cap, cellRec, cell_kp, cell_cnt);
 }
 
 void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt, const Geom &g, const uint16_t *lut,
