@@ -106,7 +106,14 @@ def main():
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="720p4")
-    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; value = their median")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions; value = their median")
+    ap.add_argument("--min-region-s", type=float, default=1.0,
+                    help="a timed region runs at least this long: the steps per region are raised above --steps when needed "
+                         "(20 steps last 0.11 s -- a 3 %% kernel change is invisible through that); `steps` in the output is the "
+                         "number actually timed per region, `steps_requested` what was asked for.  0 = exactly --steps")
+    ap.add_argument("--host-cores", type=int, default=4,
+                    help="extra leg `value_host_cores`: the same steps with the process (engine workers, slot drivers, caller) "
+                         "confined to this many cores; 0 = skip")
     ap.add_argument("--frames", type=int, default=None, help="rig frames per rank per step (default: slots x 128 images / cameras)")
     ap.add_argument("--slots", type=int, default=None, help="buffer sets in flight per rank (default 6; 12 = 6 groups x 2 on the N>1 path)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -346,6 +353,17 @@ def main():
         return dt
 
     run_steps(args.warmup, False)
+    # region length: one calibration region of --steps steps, then as many steps per region as --min-region-s needs
+    # (all ranks agree: timed_region returns the max over ranks)
+    steps_requested = args.steps
+    if args.min_region_s > 0:
+        dt_cal = timed_region(args.steps, False)
+        need = int(np.ceil(args.min_region_s / max(dt_cal / args.steps, 1e-9)))
+        if dist is not None:
+            tt = torch.tensor([need], dtype=torch.int64, device="cpu" if gloo else "cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            need = int(tt.item())
+        args.steps = max(args.steps, need)
     dts = [timed_region(args.steps, True) for _ in range(max(1, args.repeats))]
     dt = float(np.median(dts))
 
@@ -407,7 +425,8 @@ def main():
             traffic_note = "profiles/traffic.json unreadable: %s" % e
     out = {
         "metric": "multi-cam frames/sec (%d-cam %dx%d @%d kpts/cam, extract + intra-rig match)" % (NCAMS, W, H, NFEAT),
-        "value": round(value, 2), "unit": "frames/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 2), "unit": "frames/s", "n_gpus": N, "steps": args.steps, "steps_requested": steps_requested,
+        "region_s": round(dt, 4), "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_frame": round(dt / args.steps / (total_frames * IT) * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
         "repeats": len(dts), "value_min": round(total_frames * IT * args.steps / max(dts), 2),
@@ -424,13 +443,39 @@ def main():
                              "isolated_* is the same kernel with one job in flight (median of %d)" % (S, args.iso_jobs)},
         "kernel_us_per_step": {k: round(v / args.steps / len(dts), 2) for k, v in ksum.items()},
     }
+    # the whole path against the HBM roof: SURVEY 8(d)'s bytes per rig frame (every plane once per logical pass, the blur's
+    # 2 S included although this build no longer moves them) and the bytes this build's kernels really have to move
+    pairs_frame = NCAMS * (NCAMS - 1) // 2
+    b_extract = (Spx - s_last) + (Spx - S0) + Spx + 2 * Spx + K * (512 + 32) + Kc * 12 + K * 28
+    b_match = 2 * K * 32 + K * 16
+    b_frame = NCAMS * b_extract + pairs_frame * b_match
+    b_frame_build = NCAMS * sum(algorithmic_bytes(k, Spx, S0, s_last, K, Kc, info["bucket_total"]) for k in GPU_KERNELS if k != "k_knn2") \
+        + pairs_frame * algorithmic_bytes("k_knn2", Spx, S0, s_last, K, Kc, info["bucket_total"])
+    out["roofline"]["whole_path"] = {
+        "bytes_per_frame_survey_8d": int(b_frame), "achieved": round(b_frame * value / 1e9, 1), "frac": round(b_frame * value / 1e9 / HBM_PEAK_GBS, 4),
+        "bytes_per_frame_this_build": int(b_frame_build), "frac_this_build": round(b_frame_build * value / 1e9 / HBM_PEAK_GBS, 4),
+        "unit": "GB/s", "note": "frames/s x bytes per rig frame / 8 TB/s; 8(d) counts a full-plane blur (2 S per image) that is fused "
+                                "into the descriptor kernel here and never travels"}
+    # per-kernel instruction-issue floors (SQ_INSTS_VALU / SQ_INSTS_MFMA per launch from profiles/traffic.json, same sha check):
+    # a wave64 vector instruction occupies its SIMD's issue port for 4 cycles in these kernels whatever its class
+    # (profiles/r03_valu_rates.txt: 2.2 for v_add / v_and / v_xor when two waves issue them back to back, 4.1 for everything
+    # else; SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.008 quad-cycles in k_fast_cells), a 32x32x32 i8 multiply its matrix pipe for 32
+    SIMDS, CLK_HZ = 1024, 2.4e9
+    floors = {}
+    if traffic is not None:
+        for k in GPU_KERNELS:
+            e = tj.get(k, {})
+            if e.get("valu_insts_per_launch"):
+                f = {"valu_insts": int(e["valu_insts_per_launch"]), "valu_floor_us": round(e["valu_insts_per_launch"] * 4 / SIMDS / CLK_HZ * 1e6, 1)}
+                if e.get("mfma_insts_per_launch"):
+                    f["mfma_insts"] = int(e["mfma_insts_per_launch"])
+                    f["mfma_floor_us"] = round(e["mfma_insts_per_launch"] * 32 / SIMDS / CLK_HZ * 1e6, 1)
+                floors[k] = f
     if valu_insts:
-        # the bound that actually holds the dominant kernel: wave64 vector instructions issue at one per 4 cycles per SIMD
-        # (tools/valu_rates.hip); SQ_INSTS_VALU per launch from profiles/ (same sha check as the traffic figure)
-        SIMDS, CLK_HZ = 1024, 2.4e9
         floor_us = valu_insts * 4 / SIMDS / CLK_HZ * 1e6
         out["roofline"]["valu"] = {"insts_per_launch": int(valu_insts), "cycles_per_inst": 4, "simds": SIMDS, "clock_ghz": 2.4,
-                                   "floor_us": round(floor_us, 1), "frac_in_flight": round(floor_us / avg_us, 3)}
+                                   "floor_us": round(floor_us, 1), "frac_in_flight": round(floor_us / avg_us, 3),
+                                   "evidence": "profiles/r03_valu_rates.txt (tools/valu_rates.hip, 1/2/4/8 waves per SIMD)"}
     if DIST:
         out["exchange"] = {"collective": "all_to_all_single (uneven splits)", "bytes_sent_per_rank_per_step": int(exchange_bytes * IT), "rounds_per_step": IT,
                            "send_splits_rank0": send_splits}
@@ -443,9 +488,9 @@ def main():
         out["kernel_us_per_launch_isolated"] = {k: round(v, 2) for k, v in iso.items()}
         # every kernel against its own algorithmic bytes (isolated): where the path stands as a whole
         out["roofline_all_kernels_isolated"] = {
-            k: {"us": round(iso[k], 1),
-                "GBps": round(algorithmic_bytes(k, Spx, S0, s_last, K, Kc, info["bucket_total"]) *
-                              (pairs_launch if k == "k_knn2" else nimg_launch) / (iso[k] * 1e-6) / 1e9, 1)}
+            k: dict({"us": round(iso[k], 1),
+                     "GBps": round(algorithmic_bytes(k, Spx, S0, s_last, K, Kc, info["bucket_total"]) *
+                                   (pairs_launch if k == "k_knn2" else nimg_launch) / (iso[k] * 1e-6) / 1e9, 1)}, **floors.get(k, {}))
             for k in GPU_KERNELS if iso[k] > 0}
 
     if N == 1 and not DIST and not args.no_staging:
@@ -460,6 +505,28 @@ def main():
                                "value_with_upload_u8: mcorb_rig_upload_u8 from pageable memory (host copy + DMA); pcie_gbs: host->device "
                                "bytes/s in the staged region.  `value` itself keeps its inputs resident in HBM; fed from a host it is "
                                "bounded by these.")
+
+    if N == 1 and not DIST and args.host_cores > 0 and hasattr(os, "sched_setaffinity"):
+        # how much of `value` hangs on host cores (selection workers, slot drivers, track merges): the same steps from a
+        # second rig whose threads -- created under the narrowed affinity mask -- and the caller share args.host_cores cores
+        allowed = sorted(os.sched_getaffinity(0))
+        if len(allowed) > args.host_cores:
+            os.sched_setaffinity(0, set(allowed[:args.host_cores]))
+            try:
+                rig_main = rig
+                rig = mcorb.Rig(NCAMS, W, H, max_frames=fps, nslots=S, nfeatures=NFEAT, device_id=local)
+                for s_ in range(S):
+                    rig.upload(slot_imgs[s_], slot=s_)
+                run_steps(args.warmup, False)
+                dt_hc = timed_region(args.steps, False)
+                out["value_host_cores"] = {"cores": args.host_cores, "value": round(total_frames * args.steps / dt_hc, 2),
+                                           "engine_workers": rig.info().get("host_threads"),
+                                           "note": "process confined to %d of the %d cores it may use (sched_setaffinity before the rig is "
+                                                   "created); `value` itself ran with all of them" % (args.host_cores, len(allowed))}
+                rig.close()
+            finally:
+                rig = rig_main
+                os.sched_setaffinity(0, set(allowed))
 
     if N == 1 and not DIST and not args.no_cpu:
         ncpu = os.cpu_count()

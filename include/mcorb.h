@@ -167,9 +167,12 @@ int mcorb_rig_get_candidates(mcorb_rig *r, int slot, int m, int level, uint32_t 
 int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[10]);
 
 /* multi-GPU plumbing (one process per GPU; the collective itself is the
- * caller's, e.g. an RCCL all-gather over torch.distributed).
+ * caller's: bench.py's throughput path uses one RCCL all-to-all with uneven splits per round, its
+ * --exchange allgather path the all-gather SURVEY 8(e) describes; both over torch.distributed).
  * Descriptor block layout on the device: [sets][kcap][32] bytes. */
 int mcorb_rig_kcap(mcorb_rig *r);
+/* worker threads of the rig's host stage (selection, track merges): what mcorb_params.host_threads / the core budget resolved to */
+int mcorb_rig_host_threads(mcorb_rig *r);
 /* sizes of one image's device structures (what the byte counts of the measurements are made of):
  * out = {kcap, FAST cells, blur tiles, candidate slots per cell, candidate list capacity, quad-tree bucket entries,
  *        bytes of one pyramid block, levels} */

@@ -248,7 +248,9 @@ class Rig:
     def info(self):
         o = np.zeros(8, np.int32)
         _lib.check(self.L.mcorb_rig_info(self.h_rig, o.ctypes.data))
-        return dict(zip(("kcap", "cells", "tiles", "cell_cap", "cand_cap", "bucket_total", "img_bytes", "nlevels"), (int(v) for v in o)))
+        d = dict(zip(("kcap", "cells", "tiles", "cell_cap", "cand_cap", "bucket_total", "img_bytes", "nlevels"), (int(v) for v in o)))
+        d["host_threads"] = int(self.L.mcorb_rig_host_threads(self.h_rig))
+        return d
 
     def timing(self, slot=0):
         t = (C.c_float * 10)()

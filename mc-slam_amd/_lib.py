@@ -76,6 +76,7 @@ SIGNATURES = {
     "mcorb_rig_get_candidates": (_i, [_vp, _i, _i, _i, _vp, _i, _ip]),
     "mcorb_rig_last_timing": (_i, [_vp, _i, C.POINTER(_f)]),
     "mcorb_rig_kcap": (_i, [_vp]),
+    "mcorb_rig_host_threads": (_i, [_vp]),
     "mcorb_rig_info": (_i, [_vp, _vp]),
     "mcorb_rig_desc_device_ptr": (_vp, [_vp, _i]),
     "mcorb_rig_stream": (_vp, [_vp, _i]),

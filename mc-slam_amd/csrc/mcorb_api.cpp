@@ -381,6 +381,7 @@ int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[10])
 }
 
 int mcorb_rig_kcap(mcorb_rig *r) { return r ? r->rig.geom.kcap : MCORB_E_ARG; }
+int mcorb_rig_host_threads(mcorb_rig *r) { return r ? r->rig.pool_threads : MCORB_E_ARG; }
 int mcorb_rig_info(mcorb_rig *r, int32_t out[8])
 {
     if (!r || !out) return MCORB_E_ARG;
@@ -425,6 +426,16 @@ int mcorb_rig_match_external_dev_submit(mcorb_rig *r, int slot, const void *desc
     j.kind = Job::MATCH; j.nframes = nframes; j.dist_thresh = dist_thresh; j.ratio = ratio;
     j.ext_desc = desc_dev; j.ext_counts_dev = counts_dev; j.ext_total = ntotal; j.ext_sets = sets;
     j.after_stream = (hipStream_t)after_stream;
+    if (after_stream) {
+        // "everything enqueued so far on after_stream": the event is recorded HERE, on the caller's thread (the slot is
+        // idle, so its hand-off event is free); the slot's driver only makes the slot's stream wait for it.  Recorded by
+        // the driver when it dequeues the job, the event also covered whatever the caller had enqueued meanwhile, and a
+        // second thread was recording events on a stream the caller owns.
+        Slot *s = get_slot(r, slot);
+        if (!s) return MCORB_E_STATE;
+        HIPCHK(hipSetDevice(r->rig.device));
+        HIPCHK(hipEventRecord(s->ev_x, (hipStream_t)after_stream));
+    }
     return r->rig.submit(slot, j);
 }
 

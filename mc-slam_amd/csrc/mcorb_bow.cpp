@@ -15,6 +15,7 @@
 #include <fstream>
 #include <chrono>
 #include <map>
+#include <mutex>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -50,6 +51,11 @@ struct mcorb_vocab {
     // scratch of mcorb_rig_match_bow (grow-only): device index tables + result table, pinned host mirror
     int *d_mi = nullptr; float *d_my = nullptr; int2 *d_mrg = nullptr; int4 *d_mtab = nullptr, *h_mtab = nullptr;
     size_t mi_cap = 0, my_cap = 0, mrg_cap = 0, mtab_cap = 0;
+    // The scratch above belongs to the vocabulary, the launches that use it go to the calling slot's stream: two threads
+    // driving two slots with one vocabulary (the reference transforms from per-camera threads) would race on it, and a
+    // grow on one would free what the other's kernel still reads.  Every entry point that touches the scratch holds this
+    // from ensure_scratch to its final stream synchronisation.
+    std::mutex scratch_mu;
 };
 
 static void free_vocab(mcorb_vocab *v)
@@ -299,6 +305,7 @@ int mcorb_vocab_transform(mcorb_vocab *v, const uint8_t *desc, int n, int levels
 {
     if (!v || n < 0 || (n && !desc)) { set_error("transform: bad argument"); return MCORB_E_ARG; }
     HIPCHK(hipSetDevice(v->device));
+    std::lock_guard<std::mutex> scratch_lock(v->scratch_mu);
     int st = ensure_scratch(v, std::max(n, 1));
     if (st != MCORB_OK) return st;
     if (n) HIPCHK(hipMemcpy(v->d_desc, desc, (size_t)n * 32, hipMemcpyHostToDevice));
@@ -327,6 +334,7 @@ extern "C" int mcorb_rig_transform_image(mcorb_rig *r, int slot, int m, mcorb_vo
     if (v->device != r->rig.device) { set_error("vocabulary lives on another device"); return MCORB_E_ARG; }
     HIPCHK(hipSetDevice(v->device));
     const int n = s->h_nsel[m];
+    std::lock_guard<std::mutex> scratch_lock(v->scratch_mu);
     int st = ensure_scratch(v, std::max(n, 1));
     if (st != MCORB_OK) return st;
     // descriptors of image m are still resident in the slot: no host round trip
@@ -349,6 +357,7 @@ extern "C" int mcorb_rig_transform_images(mcorb_rig *r, int slot, int img0, int 
     if (v->device != R.device) { set_error("vocabulary lives on another device"); return MCORB_E_ARG; }
     HIPCHK(hipSetDevice(v->device));
     const int kcap = R.geom.kcap;
+    std::lock_guard<std::mutex> scratch_lock(v->scratch_mu);
     int st = ensure_scratch(v, nimg * kcap);
     if (st != MCORB_OK) return st;
     launch_bow_descend(s->st, s->d_desc + (size_t)img0 * kcap * 32, nimg * kcap, v->d_child_start, v->d_child_count, v->d_child_desc,
@@ -380,7 +389,11 @@ extern "C" int mcorb_rig_get_transform(mcorb_rig *r, int slot, int m, uint32_t *
 {
     if (!r || slot < 0 || slot >= (int)r->rig.slots.size()) { set_error("get transform: bad argument"); return MCORB_E_ARG; }
     Slot *s = r->rig.slots[slot];
-    if (m < 0 || m >= (int)s->bowvec.size() || !s->bowvec_ok[m]) { set_error("get transform: image not transformed"); return MCORB_E_STATE; }
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        if (s->busy) { set_error("slot busy"); return MCORB_E_STATE; }
+    }
+    if (m < 0 || m >= (int)s->bowvec_ok.size() || !s->bowvec_ok[m]) { set_error("get transform: image not transformed since the slot's last extraction"); return MCORB_E_STATE; }
     const BowImageOut &o = s->bowvec[m];
     if (nbow) *nbow = (int)o.bow_ids.size();
     if (nfv) *nfv = (int)o.fv_nodes.size();
@@ -430,7 +443,7 @@ extern "C" int mcorb_rig_match_bow_frames(mcorb_rig *r, int slot, int frame0, in
     HIPCHK(hipSetDevice(R.device));
     const int TH_LOW = 75;   // ORBextractor.h:27
     const int img0 = frame0 * C, nimg = nframes * C;
-    if ((int)s->bow.size() < R.max_frames) s->bow.resize(R.max_frames);
+    if ((int)s->bow.size() < R.max_frames) { s->bow.resize(R.max_frames); s->bow_ok.assign(R.max_frames, 0); }
 
     static const bool prof = getenv("MCORB_HOST_PROF") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -439,6 +452,7 @@ extern "C" int mcorb_rig_match_bow_frames(mcorb_rig *r, int slot, int frame0, in
 
     // 1. vocabulary descent of every descriptor of the batch (transform(..., levelsup), MultiCameraFrame.cpp:257): one
     //    launch over the slot's kcap-strided descriptor block (rows past an image's count are descended too and ignored)
+    std::lock_guard<std::mutex> scratch_lock(v->scratch_mu);
     int st = ensure_scratch(v, nimg * kcap);
     if (st != MCORB_OK) return st;
     launch_bow_descend(s->st, s->d_desc + (size_t)img0 * kcap * 32, nimg * kcap, v->d_child_start, v->d_child_count, v->d_child_desc,
@@ -657,7 +671,7 @@ extern "C" int mcorb_rig_match_bow_frames(mcorb_rig *r, int slot, int frame0, in
             out.n_rays[m] = matches[m].n_rays;
         }
     }, R.pool_threads + s->index);
-    s->bow_frames_done = std::max(s->bow_frames_done, frame0 + nframes);
+    for (int f = 0; f < nframes; f++) s->bow_ok[frame0 + f] = 1;   // exactly the frames matched by this call
     if (prof)
         fprintf(stderr, "[mcorb host prof] match_bow x%d frames: descend+sync %.0f us, feature vectors + tables %.0f, best2+copy %.0f, replay %.0f\n",
                 nframes, us(T0, T1), us(T1, T2), us(T2, T3), us(T3, now()));
@@ -671,7 +685,11 @@ extern "C" int mcorb_rig_get_bow_tracks(mcorb_rig *r, int slot, int frame, int32
     if (nwords_out) *nwords_out = 0;
     if (!r || slot < 0 || slot >= (int)r->rig.slots.size()) { set_error("bow tracks: bad argument"); return MCORB_E_ARG; }
     Slot *s = r->rig.slots[slot];
-    if (frame < 0 || frame >= (int)s->bow.size() || frame >= s->bow_frames_done) { set_error("bow tracks: frame not matched"); return MCORB_E_STATE; }
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        if (s->busy) { set_error("slot busy"); return MCORB_E_STATE; }
+    }
+    if (frame < 0 || frame >= (int)s->bow_ok.size() || !s->bow_ok[frame]) { set_error("bow tracks: frame not matched since the slot's last extraction"); return MCORB_E_STATE; }
     const BowFrameOut &o = s->bow[frame];
     const int C = r->rig.ncams, n = (int)o.n_rays.size();
     if (ntracks_out) *ntracks_out = n;

@@ -30,9 +30,11 @@ struct BucketWin { uint32_t key, val; };         // what k_compact ships per buc
 
 // Per-image table block k_compact fills in DEVICE memory; one DMA per batch brings the blocks to the host:
 // ints [0, 17) level offsets into the image's candidate list (+ the total), [17, 33) `shipped` flag per level,
-// [kTblHead, kTblHead + bucketTotal) bucket start offsets, then bucketTotal BucketWin records.
+// [kTblHead, kTblHead + bucketTotal) bucket start offsets, then -- from the next EVEN int on: the records are stored and read
+// 8 bytes at a time, and bucketTotal (a sum of nBuckets + 1 over the levels) can be odd -- bucketTotal BucketWin records.
 constexpr int kTblLvlOff = 0, kTblShipped = kMaxLevels + 1, kTblHead = 48;
-__host__ __device__ inline int tbl_ints(int bucketTotal) { return (kTblHead + 3 * bucketTotal + 15) & ~15; }
+__host__ __device__ inline int tbl_win_off(int bucketTotal) { return kTblHead + ((bucketTotal + 1) & ~1); }
+__host__ __device__ inline int tbl_ints(int bucketTotal) { return (tbl_win_off(bucketTotal) + 2 * bucketTotal + 15) & ~15; }
 
 // result of the vocabulary descent of one descriptor: word id and weight of the leaf it reached (word < 0 never
 // happens for a well-formed tree), and the node id `levelsup` levels above the leaves (FeatureVector key)

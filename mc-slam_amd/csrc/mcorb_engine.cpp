@@ -779,6 +779,7 @@ void Rig::driver(Slot *sp)
 int Rig::run_extract_phaseA(Slot &s, const Job &j)
 {
     if (j.nimg < 1 || j.nimg > max_images) { set_error("extract: bad image count"); return MCORB_E_ARG; }
+    s.invalidate_bow();   // tracks / BoW vectors of the previous batch index keypoints that are about to disappear
     s.h_overflow[0] = 0;
     HIPCHK(hipEventRecord(s.ev[0], s.st));
     launch_pyramid(s.st, s.d_pyr, geom, d_taps, resize_win, j.nimg);
@@ -822,7 +823,7 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
         const int *tb = s.tbl(m);
         const int *lo = tb + kTblLvlOff, *shp = tb + kTblShipped;
         const int *bst = tb + kTblHead;
-        const BucketWin *win = reinterpret_cast<const BucketWin *>(tb + kTblHead + geom.bucketTotal);
+        const BucketWin *win = reinterpret_cast<const BucketWin *>(tb + tbl_win_off(geom.bucketTotal));
         {
             // the DMA engine wrote these over PCIe, so they sit in DRAM, not in this core's caches: stream them in with one
             // demand load per cache line instead of taking the misses one by one below (software prefetches were
@@ -981,10 +982,8 @@ int Rig::enqueue_match(Slot &s, const Job &j, bool ctrl_on_device)
         TRY(prepare_match(s, j));
         HIPCHK(hipMemcpyAsync(s.d_ctrl, s.h_ctrl, s.ctrl_pairs_end, hipMemcpyHostToDevice, s.st));
     }
-    if (j.after_stream) {   // the block is being produced on another stream (a collective): order this stream behind it
-        HIPCHK(hipEventRecord(s.ev_x, j.after_stream));
-        HIPCHK(hipStreamWaitEvent(s.st, s.ev_x, 0));
-    }
+    if (j.after_stream)   // the block is being produced on another stream (a collective): order this stream behind what the
+        HIPCHK(hipStreamWaitEvent(s.st, s.ev_x, 0));   // caller had enqueued there at submit time (ev_x, recorded by the submit call)
     if (j.ext_counts_dev) {
         HIPCHK(hipMemcpyAsync(s.d_extcounts, j.ext_counts_dev, (size_t)j.ext_total * sizeof(int), hipMemcpyDeviceToDevice, s.st));
         HIPCHK(hipMemcpyAsync(s.h_extcounts, j.ext_counts_dev, (size_t)j.ext_total * sizeof(int), hipMemcpyDeviceToHost, s.st));

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -152,10 +153,17 @@ struct Slot {
     std::vector<std::vector<uint32_t>> m_idx1, m_idx2;   // per pair
     std::vector<std::vector<int32_t>> tracks;            // per frame, ncams ints per track
     std::vector<int> mergeable;
+    // cached BoW results of the images the slot holds NOW: a new extraction clears the flags (run_extract_phaseA), the
+    // getters refuse frames / images that were not matched / transformed since
     std::vector<BowFrameOut> bow;   // per frame
-    int bow_frames_done = 0;
+    std::vector<uint8_t> bow_ok;    // per frame: bow[f] belongs to the current extraction
     std::vector<BowImageOut> bowvec;   // per image
     std::vector<uint8_t> bowvec_ok;
+    void invalidate_bow()
+    {
+        std::fill(bow_ok.begin(), bow_ok.end(), (uint8_t)0);
+        std::fill(bowvec_ok.begin(), bowvec_ok.end(), (uint8_t)0);
+    }
     float timing[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<int> match_sets, match_counts;   // per (frame, cam) of the last match: set index, descriptor count
     bool match_external = false;

@@ -4,8 +4,9 @@
 // images (grid.y or grid.z = image index) so that launch cost is shared by all
 // cameras and frames of a batch.  All arithmetic is integer and bit-exact with
 // the reference's OpenCV CPU path as restated in oracle/ (see DESIGN.md).
-// Nothing here is GEMM-shaped: no MFMA.  The levers are LDS tiles, packed
-// 16-bit min/max, wave64 ballots and popcounts.
+// The levers are LDS tiles, packed 16-bit min/max, wave64 ballots and popcounts; one kernel is
+// GEMM-shaped: the all-pairs Hamming k-NN has an exact dense formulation and runs on the matrix
+// cores (k_knn2: v_mfma_i32_32x32x32_i8 on +-64 expanded descriptors).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -789,7 +790,7 @@ __global__ __launch_bounds__(kCompactWG) void k_compact(const uint32_t *__restri
         if (bkey[code] == (((uint32_t)cand_resp(p) << 23) | (uint32_t)(kPickOrderMask - order))) bval[code] = p;   // keys are unique
     });
     __syncthreads();   // the workgroup's own global stores are visible to it after the barrier
-    uint2 *bb_out = reinterpret_cast<uint2 *>(tb + kTblHead + g.bucketTotal) + L.bucket0;   // BucketWin {key, val}
+    uint2 *bb_out = reinterpret_cast<uint2 *>(tb + tbl_win_off(g.bucketTotal)) + L.bucket0;   // BucketWin {key, val}
     for (int b = tid; b < B; b += kCompactWG) bb_out[b] = uint2{bkey[b], bval[b]};
     // The list itself goes over PCIe only when the host can need it: DistributeOctTree divides a depth-D node (one
     // bucket) only after every node reached depth D with fewer than N nodes in total, and at that point the node count

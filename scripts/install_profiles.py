@@ -43,7 +43,7 @@ out = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZ
                       "and 1-byte-per-lane streaming reads on this gfx950 (profiles/%s_fetch_calibration.txt), WRITE_SIZE is exact" % tag,
        "kernels_sha256_16": sha, "config": bench["config"]["name"], "round": tag}
 # vector instructions per launch (SQ_INSTS_VALU), for the instruction-issue bound bench.py reports beside the HBM one
-valu, cur = {}, None
+valu, mfma, cur = {}, {}, None
 sq = os.path.join(P, tag + "_pmc_sq_counters.txt")
 if os.path.exists(sq):
     for line in open(sq):
@@ -51,6 +51,8 @@ if os.path.exists(sq):
             cur = line.split()[0]
         elif line.split()[0] == "SQ_INSTS_VALU" and cur not in valu:
             valu[cur] = float(line.split()[2])
+        elif line.split()[0] == "SQ_INSTS_MFMA" and cur not in mfma:
+            mfma[cur] = float(line.split()[2])
 for k in sorted(set(f) & set(w)):
     if not k.startswith("k_"):
         continue
@@ -59,6 +61,8 @@ for k in sorted(set(f) & set(w)):
               "write_size_kib_per_launch": w[k], "images_per_launch": NIMG}
     if k in valu:
         out[k]["valu_insts_per_launch"] = int(valu[k] * mult)
+    if mfma.get(k):
+        out[k]["mfma_insts_per_launch"] = int(mfma[k] * mult)
     if mult > 1:
         out[k]["note"] = "sum of the 7 level launches"
 json.dump(out, open(os.path.join(P, "traffic.json"), "w"), indent=1)

@@ -5,6 +5,8 @@ repository, so the oracle restates the published algorithm
 synthetic vocabulary trees -- parity for this row is unpinned like the rest of the path."""
 import os
 
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -173,6 +175,45 @@ def test_bow_batched_frames_transform_and_undistorted_rows():
     # the single-frame entry point still answers with the raw rows
     tr, nr, words = voc.match_rig_frame(rig, 2, levelsup=2)
     assert np.array_equal(tr, got[2][0]) and np.array_equal(nr, got[2][1]) and np.array_equal(words, got[2][2])
+    rig.close()
+
+
+@pytest.mark.gpu
+def test_bow_results_are_invalidated_by_partial_matches_and_new_extractions():
+    """The cached BoW results belong to the images a slot holds NOW (round-2 advisor finding: the getters answered with
+    MCORB_OK for frames that were never matched, and with the previous batch's tracks after a new extraction)."""
+    import mcorb
+    from importlib import import_module
+    lib = import_module("mc-slam_amd")._lib
+    C, W, H, N, F = 2, 640, 480, 500, 4
+    rig = mcorb.Rig(C, W, H, F, 1, nfeatures=N)
+    rig.upload([mcorb.synth_rig_frame(f, C, c, W, H) for f in range(F) for c in range(C)])
+    rig.extract(F * C)
+    v = O.make_vocabulary(10, 3, seed=5)
+    voc = mcorb.ORBVocabulary().create(**v)
+
+    def get_tracks(f):
+        cap = rig.kcap * C
+        tr, nr, w = np.zeros((cap, C), np.int32), np.zeros(cap, np.int32), np.zeros(cap, np.uint32)
+        nt, nw = ctypes.c_int(), ctypes.c_int()
+        return rig.L.mcorb_rig_get_bow_tracks(rig.h_rig, 0, f, tr.ctypes.data, nr.ctypes.data, cap, ctypes.byref(nt), w.ctypes.data, cap, ctypes.byref(nw))
+
+    def get_transform(m):
+        cap = rig.kcap
+        ids, vals = np.zeros(cap, np.uint32), np.zeros(cap, np.float64)
+        nodes, offs, feats = np.zeros(cap, np.uint32), np.zeros(cap + 1, np.int32), np.zeros(cap, np.int32)
+        nb, nf = ctypes.c_int(), ctypes.c_int()
+        return rig.L.mcorb_rig_get_transform(rig.h_rig, 0, m, ids.ctypes.data, vals.ctypes.data, cap, ctypes.byref(nb), nodes.ctypes.data,
+                                             offs.ctypes.data, cap, ctypes.byref(nf), feats.ctypes.data, cap)
+    voc.match_rig_frames(rig, 2, 2, levelsup=2)               # frames [2, 4) only
+    assert get_tracks(2) == 0 and get_tracks(3) == 0
+    assert get_tracks(0) == lib.E_STATE and get_tracks(1) == lib.E_STATE, "frames 0, 1 were never matched"
+    voc.transform_rig_images(rig, 2, 3, levelsup=2)           # images 2 .. 4 only
+    assert get_transform(3) == 0 and get_transform(0) == lib.E_STATE and get_transform(5) == lib.E_STATE
+    rig.extract(F * C)                                        # a new extraction on the slot: everything cached is stale
+    assert get_tracks(2) == lib.E_STATE and get_transform(3) == lib.E_STATE
+    voc.match_rig_frames(rig, 0, 1, levelsup=2)
+    assert get_tracks(0) == 0 and get_tracks(2) == lib.E_STATE
     rig.close()
 
 

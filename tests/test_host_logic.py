@@ -161,3 +161,18 @@ def test_representative_descriptor_matches_oracle():
             d = np.stack([base ^ (rng.integers(0, 256, 32, dtype=np.uint8) & rng.integers(0, 256, 32, dtype=np.uint8)
                                   & rng.integers(0, 256, 32, dtype=np.uint8)) for _ in range(n)])
             assert pkg.representative_desc(d) == O.representative_desc(d)
+
+
+def test_opencv_flavour_of_the_adapter_is_well_formed():
+    """SYNTAX ONLY -- pins nothing.  OpenCV is not in this image, so the -DMCORB_WITH_OPENCV half of
+    include/mcorb_adapter.hpp (the code a maintainer would compile next to MC-SLAM) is compiled against
+    tests/cpp/cvmock, this repository's own minimal stand-in for the cv:: declarations it touches
+    (InputArray / OutputArray / Mat / Mat_ / Range / KeyPoint).  A green test says the C++ is well-formed against
+    those signatures; what OpenCV computes is not involved."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-I" + os.path.join(root, "tests", "cpp", "cvmock"),
+           "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "adapter_opencv_syntax.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
