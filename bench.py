@@ -358,7 +358,7 @@ def main():
     steps_requested = args.steps
     if args.min_region_s > 0:
         dt_cal = timed_region(args.steps, False)
-        need = int(np.ceil(args.min_region_s / max(dt_cal / args.steps, 1e-9)))
+        need = int(np.ceil(1.1 * args.min_region_s / max(dt_cal / args.steps, 1e-9)))   # (+10 %: the calibration region runs a little slow)
         if dist is not None:
             tt = torch.tensor([need], dtype=torch.int64, device="cpu" if gloo else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -331,6 +331,16 @@ int mcorb_rig_obtain_lf_features(mcorb_rig *r, int slot, int frame, const int32_
                                  const mcorb_keypoint *const *kps_undist, int total_feats, mcorb_lf_feature *out, int cap,
                                  int *n_out, int *intramatch_size_out, int *mono_size_out, uint32_t *words_fil, int cap_words,
                                  int *nwords_fil_out);
+/* The same for all frames [frame0, frame0 + nframes) of a slot in one call, one worker-pool task per frame (FrontEnd.cpp:1024
+ * calls obtainLfFeatures once per frame; a batch holds many).  tracks / words: the frames' arrays back to back -- ntracks[f]
+ * tracks (ncams ints each) and, if words != NULL, as many words per frame; seg_masks / kps_undist: nframes * ncams pointers
+ * (index f * ncams + cam) or NULL; out: nframes blocks of `cap` entries; words_fil (may be NULL): nframes blocks of cap_words;
+ * n_out / intramatch_size_out / mono_size_out / nwords_fil_out: nframes entries each.  Returns the first failing frame's status. */
+int mcorb_rig_obtain_lf_features_frames(mcorb_rig *r, int slot, int frame0, int nframes, const int32_t *tracks, const int32_t *ntracks,
+                                        const uint32_t *words, const mcorb_camera *cams, const float *const *seg_masks, int seg_stride,
+                                        const mcorb_keypoint *const *kps_undist, int total_feats, mcorb_lf_feature *out, int cap,
+                                        int *n_out, int *intramatch_size_out, int *mono_size_out, uint32_t *words_fil, int cap_words,
+                                        int *nwords_fil_out);
 
 /* ------------------------------------------------------------------------- */
 /* Host stages exposed for the CPU test-suite (no device needed)              */

@@ -202,6 +202,7 @@ class Rig:
             for c in range(Cn):
                 if seg_masks[c] is not None:
                     a = np.ascontiguousarray(seg_masks[c], np.float32)
+                    assert stride in (0, a.shape[1]), "all segmentation masks must share one row stride"
                     keep.append(a)
                     segp[c] = a.ctypes.data
                     stride = a.shape[1]
@@ -225,6 +226,55 @@ class Rig:
                                                        total_feats, out.ctypes.data, cap, C.byref(n), C.byref(ni), C.byref(nm),
                                                        wf.ctypes.data, len(wf), C.byref(nw)))
         return out[:n.value].copy(), ni.value, nm.value, wf[:nw.value].copy()
+
+    def obtain_lf_features_frames(self, frame0, tracks_per_frame, K_mats, R_mats, t_mats, words_per_frame=None, seg_masks=None,
+                                  kps_undist=None, total_feats=3000, slot=0):
+        """obtainLfFeatures for frames [frame0, frame0 + len(tracks_per_frame)) of the slot in ONE call (one worker-pool task per
+        frame).  seg_masks / kps_undist: lists indexed frame * ncams + cam (None entries allowed for masks).  Returns a list of
+        (features, intramatch_size, mono_size, words_fil), one per frame."""
+        Cn, F = self.ncams, len(tracks_per_frame)
+        trs = [np.ascontiguousarray(t, np.int32).reshape(-1, Cn) for t in tracks_per_frame]
+        nt = np.array([len(t) for t in trs], np.int32)
+        tracks = np.ascontiguousarray(np.concatenate(trs) if nt.sum() else np.zeros((0, Cn), np.int32))
+        cams = (_lib.Camera * Cn)()
+        for c in range(Cn):
+            K = np.asarray(K_mats[c], np.float64).reshape(3, 3)
+            Rt = np.hstack([np.asarray(R_mats[c], np.float64).reshape(3, 3), np.asarray(t_mats[c], np.float64).reshape(3, 1)])
+            cams[c].K[:] = K.ravel().tolist()
+            cams[c].Rt[:] = Rt.ravel().tolist()
+        keep, segp, stride = [], None, 0
+        if seg_masks is not None:
+            segp = (C.c_void_p * (F * Cn))()
+            for i in range(F * Cn):
+                if seg_masks[i] is not None:
+                    a = np.ascontiguousarray(seg_masks[i], np.float32)
+                    assert stride in (0, a.shape[1]), "all segmentation masks must share one row stride"
+                    keep.append(a)
+                    segp[i] = a.ctypes.data
+                    stride = a.shape[1]
+        undp = None
+        if kps_undist is not None:
+            undp = (C.c_void_p * (F * Cn))()
+            for i in range(F * Cn):
+                a = np.ascontiguousarray(kps_undist[i], _lib.KP_DTYPE)
+                keep.append(a)
+                undp[i] = a.ctypes.data
+        wp = None
+        if words_per_frame is not None:
+            ws = [np.ascontiguousarray(w, np.uint32)[:n] for w, n in zip(words_per_frame, nt)]
+            assert all(len(w) == n for w, n in zip(ws, nt)), "one word per track"
+            words = np.ascontiguousarray(np.concatenate(ws) if nt.sum() else np.zeros(0, np.uint32))
+            keep.append(words)
+            wp = words.ctypes.data
+        cap = Cn * self.kcap + int(nt.max(initial=0)) + 1
+        capw = int(nt.max(initial=0)) + 1
+        out = np.zeros((F, cap), _lib.LF_DTYPE)
+        wf = np.zeros((F, capw), np.uint32)
+        n, ni, nm, nw = (np.zeros(F, np.int32) for _ in range(4))
+        _lib.check(self.L.mcorb_rig_obtain_lf_features_frames(self.h_rig, slot, frame0, F, tracks.ctypes.data, nt.ctypes.data, wp, cams, segp,
+                                                              stride, undp, total_feats, out.ctypes.data, cap, n.ctypes.data, ni.ctypes.data,
+                                                              nm.ctypes.data, wf.ctypes.data, capw, nw.ctypes.data))
+        return [(out[f, :n[f]].copy(), int(ni[f]), int(nm[f]), wf[f, :nw[f]].copy()) for f in range(F)]
 
     def level_size(self, level):
         w, h = C.c_int(), C.c_int()

@@ -108,6 +108,7 @@ SIGNATURES = {
     "mcorb_rig_match_bow_frames": (_i, [_vp, _i, _i, _i, _vp, _i, C.c_double, _vp]),
     "mcorb_rig_get_bow_tracks": (_i, [_vp, _i, _i, _vp, _vp, _i, _ip, _vp, _i, _ip]),
     "mcorb_rig_obtain_lf_features": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _ip, _ip, _ip, _vp, _i, _ip]),
+    "mcorb_rig_obtain_lf_features_frames": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "mcorb_host_select": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i]),
     "mcorb_host_resize_axis": (_i, [_i, _i, _i, _vp]),
     "mcorb_host_triangulate": (_i, [_vp, _vp, _i, _vp]),

@@ -465,6 +465,11 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     if (getenv("MCORB_HOST_THREADS")) nthreads = atoi(getenv("MCORB_HOST_THREADS"));
     nthreads = std::max(1, std::min(nthreads, 64));
     blur_planes = p.orientation != 0 || getenv("MCORB_BLUR_PLANES") != nullptr;
+    // Device -> host copies of the tables and the descriptors: the runtime's hipMemcpyAsync (a blit kernel on this stack) or
+    // k_copy_to_host (a 24-workgroup kernel of ours).  Measured (profiles/r03_copy_kernel_ab.txt): with six slots in flight the
+    // runtime's copy gives 4-6 % more frames/s although k_expand / k_knn2 run stretched beside it; with one slot (latency mode)
+    // ours keeps k_expand at 12 us instead of 150 and the frame a few % shorter.  MCORB_COPY_KERNEL=0|1 overrides.
+    copy_kernel = getenv("MCORB_COPY_KERNEL") ? atoi(getenv("MCORB_COPY_KERNEL")) != 0 : nslots == 1;
     pool = new WorkerPool(nthreads);
     pool_threads = nthreads;
     for (int i = 0; i < nthreads + nslots; i++) scratch.push_back(new SelectScratch);   // workers, then one per slot's submitting thread
@@ -793,7 +798,8 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
     launch_compact(side ? s.st_copy : s.st, s.d_cellkp, s.d_cellcnt, geom, d_lut, s.d_sorted, s.h_cand, s.d_tbl, s.h_overflow, j.nimg);
     HIPCHK(hipEventRecord(s.ev_c, side ? s.st_copy : s.st));
     if (!side) HIPCHK(hipStreamWaitEvent(s.st_copy, s.ev_c, 0));
-    HIPCHK(hipMemcpyAsync(s.h_tbl, s.d_tbl, (size_t)j.nimg * s.tbl_ints_per_image * sizeof(int), hipMemcpyDeviceToHost, s.st_copy));
+    if (!copy_kernel) HIPCHK(hipMemcpyAsync(s.h_tbl, s.d_tbl, (size_t)j.nimg * s.tbl_ints_per_image * sizeof(int), hipMemcpyDeviceToHost, s.st_copy));
+    else launch_copy_to_host(s.st_copy, s.d_tbl, s.h_tbl, (size_t)j.nimg * s.tbl_ints_per_image * sizeof(int));
     HIPCHK(hipEventRecord(s.ev[3], s.st_copy));
     // Reference mode blurs inside the descriptor kernel, only around the kept keypoints (k_describe_fused).  Whole
     // blurred planes are made when the rotated taps of the orientation mode need them, when MCORB_BLUR_PLANES asks for
@@ -910,7 +916,8 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
         TRY(enqueue_match(s, j, true));
         HIPCHK(hipStreamWaitEvent(s.st_dma, s.ev[9], 0));
     }
-    HIPCHK(hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)nimg * geom.kcap * 32, hipMemcpyDeviceToHost, s.st_dma));
+    if (!copy_kernel) HIPCHK(hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)nimg * geom.kcap * 32, hipMemcpyDeviceToHost, s.st_dma));
+    else launch_copy_to_host(s.st_dma, s.d_desc, s.h_desc, (size_t)nimg * geom.kcap * 32);
     if (params.orientation)
         HIPCHK(hipMemcpyAsync(s.h_angles, s.d_angles, (size_t)nimg * geom.kcap * sizeof(float), hipMemcpyDeviceToHost, s.st_dma));
     if (then_match && !d2h_late) TRY(enqueue_match(s, j, true));

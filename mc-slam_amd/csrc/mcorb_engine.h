@@ -220,6 +220,7 @@ public:
     void merge_tracks(Slot &s, int f, const EpipolarGate *gate, std::vector<int32_t> &tr, int &mergeable_out) const;
 
 private:
+    bool copy_kernel = false;  // D2H of tables / descriptors by k_copy_to_host instead of hipMemcpyAsync (see Rig::init)
     bool blur_planes = false;  // k_blur runs with every job (orientation mode / MCORB_BLUR_PLANES); otherwise blur is fused into k_describe_fused
     void driver(Slot *s);
     int execute(Slot &s, const Job &j);

@@ -43,6 +43,9 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
                  int kcap, void *expanded, int *lcounts, uint2 *part, float dist_thresh, float ratio, KnnRow *out, uint32_t *mlist,
                  int *mcount, hipEvent_t ev_exp, hipEvent_t ev_mid);   // events (optional): after k_expand, after k_knn2
 
+// device -> host-mapped pinned memory with a small grid (instead of the runtime's blit kernel); sizes rounded up to 16 bytes
+void launch_copy_to_host(hipStream_t st, const void *src_dev, void *dst_host_mapped, size_t bytes);
+
 // all frames [0, nframes) of a batch whose first image is img0 of `desc` (kcap-strided sets); tables indexed by the
 // batch-local image index f * ncams + c (see k_bow_best2)
 void launch_bow_best2(hipStream_t st, const uint8_t *desc, int img0, int kcap, int ncams, int nframes, const float *yv,

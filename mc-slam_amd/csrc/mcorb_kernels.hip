@@ -1716,6 +1716,47 @@ __global__ __launch_bounds__(256) void k_bow_best2(const uint8_t *__restrict__ d
 }
 
 // ---------------------------------------------------------------------------
+// Device -> pinned host copy as a SMALL kernel.  hipMemcpyAsync to pinned memory runs as a blit kernel on this stack
+// (__amd_rocclr_copyBuffer; HSA_ENABLE_SDMA changes nothing), and the kernel of the job that runs beside it is stretched
+// to the copy's length (k_expand: 12 us alone, 150 us beside the descriptor read-back).  The link moves ~50 GB/s whatever
+// feeds it; kCopyWG workgroups looping over the buffer with 16-byte accesses, four loads in flight per lane, feed it as
+// well and leave the neighbour alone (k_expand 23 us).  Used for single-slot rigs only: with six slots in flight the
+// runtime's copy still gives 4-6 % more frames/s (profiles/r03_copy_kernel_ab.txt; the smaller the grid the closer: 1024
+// workgroups 30.7 k, 128: 30.9 k, 24: 32.3 k, 4: 33.5 k, runtime 34.0 k frames/s).
+// ---------------------------------------------------------------------------
+constexpr int kCopyWG = 24;
+__global__ __launch_bounds__(256) void k_copy_to_host(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16)
+{
+    const v4i *s = reinterpret_cast<const v4i *>(src);
+    v4i *d = reinterpret_cast<v4i *>(dst);
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {   // four 16-byte loads in flight per lane
+        const v4i a = __builtin_nontemporal_load(s + i), b = __builtin_nontemporal_load(s + i + stride);
+        const v4i c = __builtin_nontemporal_load(s + i + 2 * stride), e = __builtin_nontemporal_load(s + i + 3 * stride);
+        __builtin_nontemporal_store(a, d + i);
+        __builtin_nontemporal_store(b, d + i + stride);
+        __builtin_nontemporal_store(c, d + i + 2 * stride);
+        __builtin_nontemporal_store(e, d + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) {
+        const v4i v = __builtin_nontemporal_load(s + i);
+        __builtin_nontemporal_store(v, d + i);
+    }
+}
+
+void launch_copy_to_host(hipStream_t st, const void *src_dev, void *dst_host_mapped, size_t bytes)
+{
+    const size_t n16 = (bytes + 15) / 16;   // both buffers are allocated in multiples of 16 bytes
+    if (!n16) return;
+    static const int wg_env = getenv("MCORB_COPY_WG") ? atoi(getenv("MCORB_COPY_WG")) : 0;
+    const size_t cap = wg_env > 0 ? (size_t)wg_env : (size_t)kCopyWG;
+    const int wgs = (int)((n16 + 255) / 256 < cap ? (n16 + 255) / 256 : cap);
+    hipLaunchKernelGGL(k_copy_to_host, dim3(wgs), dim3(256), 0, st, reinterpret_cast<const uint4 *>(src_dev),
+                       reinterpret_cast<uint4 *>(dst_host_mapped), n16);
+}
+
+// ---------------------------------------------------------------------------
 // launch wrappers
 // ---------------------------------------------------------------------------
 hipError_t upload_umax(const int umax[16]) { return hipMemcpyToSymbol(HIP_SYMBOL(c_umax), umax, 16 * sizeof(int)); }

@@ -9,14 +9,16 @@
 // puts them -- that IS the reference's order).
 // Triangulation: cv::sfm::triangulatePoints is un-vendored third-party code (opencv_contrib / libmv): two views -> the 4x4 DLT
 // design matrix, more views -> the 3n x (4+n) "x = alpha P X" design, null vector by SVD (cv::SVD::solveZ).  Restated here with
-// a one-sided Jacobi SVD in FP64: the null vector of a full-column-rank-minus-one matrix is unique up to scale, so any
-// backward-stable method returns the same point to ~1e-12 relative; parity for this step is tolerance-based (1e-9) and UNPINNED.
+// the smallest eigenvector of the design's Gram matrix in FP64 (inverse iteration): the null vector of a
+// full-column-rank-minus-one matrix is unique up to scale, so any stable method returns the same point to ~1e-11 relative;
+// parity for this step is tolerance-based (1e-9) and UNPINNED.
 #include <math.h>
 #include <string.h>
 
 #include <algorithm>
 #include <functional>
 #include <numeric>
+#include <string>
 #include <vector>
 
 #include "mcorb_engine.h"
@@ -25,47 +27,69 @@ using namespace mcorb;
 
 namespace {
 
-// right singular vector of the smallest singular value of the m x n matrix A (row-major, m >= n): one-sided Jacobi
-// (Hestenes): rotate column pairs until all are mutually orthogonal, accumulating the rotations in V
-void null_vector(std::vector<double> &A, int m, int n, double *x)
+// right singular vector of the smallest singular value of the m x n matrix A (row-major, m >= n, n <= 20)
+// = eigenvector of the smallest eigenvalue of G = A^T A, found by inverse iteration: G + delta I is factored ONCE (LU with
+// partial pivoting, n^3 / 3 multiplications), every further step is two triangular solves.  The design matrices of the
+// triangulation have one singular value far below the rest (zero for exact correspondences), so the iteration contracts by
+// lambda_1 / lambda_2 per step -- a handful of steps; grossly wrong correspondences (ratio near 1) take more, the loop runs
+// until two successive iterates agree to 1e-15.  Accuracy: eps |G| / (lambda_2 - lambda_1) on the unit vector, 1e-12 .. 1e-11
+// for this geometry (the one-sided Jacobi SVD it replaces worked on A itself, eps / sigma_2, at 50 x the cost: 60 sweeps
+// of 6 .. 28 column pairs per track were 10 of the 13 ms a 4-camera frame took in round 2).  The test against LAPACK's SVD
+// (600 cases of 2 .. 6 views, small and gross noise) holds its 1e-9.
+constexpr int kLfMaxN = 4 + MCORB_MAX_CAMS, kLfMaxM = 3 * MCORB_MAX_CAMS;
+void null_vector(const double *A, int m, int n, double *x)
 {
-    std::vector<double> V((size_t)n * n, 0.0);
-    for (int i = 0; i < n; i++) V[(size_t)i * n + i] = 1.0;
-    for (int sweep = 0; sweep < 60; sweep++) {
-        double off = 0.0;
-        for (int p = 0; p < n - 1; p++)
-            for (int q = p + 1; q < n; q++) {
-                double a = 0, b = 0, c = 0;
-                for (int i = 0; i < m; i++) {
-                    const double ap = A[(size_t)i * n + p], aq = A[(size_t)i * n + q];
-                    a += ap * ap; b += aq * aq; c += ap * aq;
-                }
-                if (c == 0.0) continue;
-                off = std::max(off, fabs(c) / sqrt(std::max(a * b, 1e-300)));
-                const double zeta = (b - a) / (2.0 * c);
-                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
-                for (int i = 0; i < m; i++) {
-                    const double ap = A[(size_t)i * n + p], aq = A[(size_t)i * n + q];
-                    A[(size_t)i * n + p] = cs * ap - sn * aq;
-                    A[(size_t)i * n + q] = sn * ap + cs * aq;
-                }
-                for (int i = 0; i < n; i++) {
-                    const double vp = V[(size_t)i * n + p], vq = V[(size_t)i * n + q];
-                    V[(size_t)i * n + p] = cs * vp - sn * vq;
-                    V[(size_t)i * n + q] = sn * vp + cs * vq;
-                }
-            }
-        if (off < 1e-15) break;
+    double G[kLfMaxN * kLfMaxN], LU[kLfMaxN * kLfMaxN];
+    int piv[kLfMaxN];
+    double tr = 0.0;
+    for (int p = 0; p < n; p++)
+        for (int q = p; q < n; q++) {
+            double sacc = 0.0;
+            for (int i = 0; i < m; i++) sacc += A[i * n + p] * A[i * n + q];
+            G[p * n + q] = G[q * n + p] = sacc;
+            if (p == q) tr += sacc;
+        }
+    if (!(tr > 0.0)) { for (int i = 0; i < n; i++) x[i] = i == n - 1 ? 1.0 : 0.0; return; }
+    const double delta = 1e-14 * tr;   // keeps the factorisation away from an exactly singular matrix
+    for (int i = 0; i < n * n; i++) LU[i] = G[i];
+    for (int i = 0; i < n; i++) LU[i * n + i] += delta;
+    for (int k = 0; k < n; k++) {
+        int pk = k;
+        for (int i = k + 1; i < n; i++) if (fabs(LU[i * n + k]) > fabs(LU[pk * n + k])) pk = i;
+        piv[k] = pk;
+        if (pk != k) for (int j = 0; j < n; j++) std::swap(LU[k * n + j], LU[pk * n + j]);
+        double d = LU[k * n + k];
+        if (fabs(d) < 1e-300) { d = d < 0 ? -1e-300 : 1e-300; LU[k * n + k] = d; }
+        const double inv = 1.0 / d;
+        for (int i = k + 1; i < n; i++) {
+            const double f = LU[i * n + k] * inv;
+            LU[i * n + k] = f;
+            if (f != 0.0) for (int j = k + 1; j < n; j++) LU[i * n + j] -= f * LU[k * n + j];
+        }
     }
-    int best = 0;
-    double bn = 1e300;
-    for (int j = 0; j < n; j++) {
-        double s = 0;
-        for (int i = 0; i < m; i++) s += A[(size_t)i * n + j] * A[(size_t)i * n + j];
-        if (s < bn) { bn = s; best = j; }
+    double v[kLfMaxN], y[kLfMaxN];
+    for (int i = 0; i < n; i++) v[i] = 1.0 / sqrt((double)n) * (1.0 + 0.01 * i);   // any start with a component along the answer
+    for (int it = 0; it < 400; it++) {
+        for (int i = 0; i < n; i++) y[i] = v[i];
+        for (int k = 0; k < n; k++)            // P (all row exchanges first: the multipliers sit in their final rows)
+            if (piv[k] != k) std::swap(y[k], y[piv[k]]);
+        for (int k = 0; k < n; k++)            // L
+            for (int i = k + 1; i < n; i++) y[i] -= LU[i * n + k] * y[k];
+        for (int k = n - 1; k >= 0; k--) {     // U
+            double t = y[k];
+            for (int j = k + 1; j < n; j++) t -= LU[k * n + j] * y[j];
+            y[k] = t / LU[k * n + k];
+        }
+        double nn = 0.0, dotp = 0.0;
+        for (int i = 0; i < n; i++) nn += y[i] * y[i];
+        nn = 1.0 / sqrt(nn);
+        for (int i = 0; i < n; i++) { y[i] *= nn; dotp += y[i] * v[i]; }
+        const double sgn = dotp < 0 ? -1.0 : 1.0;
+        double diff = 0.0;
+        for (int i = 0; i < n; i++) { y[i] *= sgn; diff = std::max(diff, fabs(y[i] - v[i])); v[i] = y[i]; }
+        if (it > 0 && diff < 1e-15) break;
     }
-    for (int i = 0; i < n; i++) x[i] = V[(size_t)i * n + best];
+    for (int i = 0; i < n; i++) x[i] = v[i];
 }
 
 // cv::sfm::triangulatePoints for one point seen in nv views: x = normalised image coordinates, P = 3x4 [R|t] (row-major)
@@ -73,7 +97,7 @@ void triangulate(const double *x, const double *const *P, int nv, double X[3])
 {
     double h[4];
     if (nv == 2) {   // triangulateDLT
-        std::vector<double> D(16);
+        double D[16];
         for (int i = 0; i < 4; i++) {
             D[0 * 4 + i] = x[0] * P[0][8 + i] - P[0][0 + i];
             D[1 * 4 + i] = x[1] * P[0][8 + i] - P[0][4 + i];
@@ -83,7 +107,8 @@ void triangulate(const double *x, const double *const *P, int nv, double X[3])
         null_vector(D, 4, 4, h);
     } else {         // triangulateNViews: [-P_i | x_i in column 4+i] (X, alpha_1..alpha_n)^T = 0
         const int m = 3 * nv, n = 4 + nv;
-        std::vector<double> D((size_t)m * n, 0.0), sol(n);
+        double D[kLfMaxM * kLfMaxN], sol[kLfMaxN];
+        for (int i = 0; i < m * n; i++) D[i] = 0.0;
         for (int i = 0; i < nv; i++) {
             for (int jj = 0; jj < 3; jj++)
                 for (int ii = 0; ii < 4; ii++) D[(size_t)(3 * i + jj) * n + ii] = -P[i][4 * jj + ii];
@@ -91,7 +116,7 @@ void triangulate(const double *x, const double *const *P, int nv, double X[3])
             D[(size_t)(3 * i + 1) * n + 4 + i] = x[2 * i + 1];
             D[(size_t)(3 * i + 2) * n + 4 + i] = 1.0;
         }
-        null_vector(D, m, n, sol.data());
+        null_vector(D, m, n, sol);
         for (int i = 0; i < 4; i++) h[i] = sol[i];
     }
     for (int i = 0; i < 3; i++) X[i] = h[i] / h[3];   // homogeneousToEuclidean
@@ -109,25 +134,20 @@ extern "C" int mcorb_host_triangulate(const double *x, const double *P, int nv, 
     return MCORB_OK;
 }
 
-extern "C" int mcorb_rig_obtain_lf_features(mcorb_rig *r, int slot, int frame, const int32_t *tracks, int ntracks,
-                                            const uint32_t *words, const mcorb_camera *cams, const float *const *seg_masks,
-                                            int seg_stride, const mcorb_keypoint *const *kps_undist, int total_feats,
-                                            mcorb_lf_feature *out, int cap, int *n_out, int *intramatch_size_out,
-                                            int *mono_size_out, uint32_t *words_fil, int cap_words, int *nwords_fil_out)
+// obtainLfFeatures of one frame of a slot.  parallel_tri: spread the triangulations over the worker pool (a single frame per
+// call); the batched entry point runs whole frames as pool tasks instead and passes false.
+static int lf_one_frame(Rig &R, Slot *s, int slot, int frame, const int32_t *tracks, int ntracks, const uint32_t *words,
+                        const mcorb_camera *cams, const float *const *seg_masks, int seg_stride, const mcorb_keypoint *const *kps_undist,
+                        int total_feats, mcorb_lf_feature *out, int cap, int *n_out, int *intramatch_size_out, int *mono_size_out,
+                        uint32_t *words_fil, int cap_words, int *nwords_fil_out, bool parallel_tri)
 {
     if (n_out) *n_out = 0;
     if (intramatch_size_out) *intramatch_size_out = 0;
     if (mono_size_out) *mono_size_out = 0;
     if (nwords_fil_out) *nwords_fil_out = 0;
-    if (!r || slot < 0 || slot >= (int)r->rig.slots.size() || ntracks < 0 || (ntracks && !tracks) || !cams || !out || cap < 0) {
+    if (ntracks < 0 || (ntracks && !tracks) || !cams || !out || cap < 0) {
         set_error("obtain_lf_features: bad argument");
         return MCORB_E_ARG;
-    }
-    Rig &R = r->rig;
-    Slot *s = R.slots[slot];
-    {
-        std::lock_guard<std::mutex> lk(s->m);
-        if (s->busy) { set_error("slot busy"); return MCORB_E_STATE; }
     }
     const int C = R.ncams, kcap = R.geom.kcap;
     if (frame < 0 || (frame + 1) * C > s->nimg_done) { set_error("obtain_lf_features: frame not extracted"); return MCORB_E_STATE; }
@@ -189,8 +209,8 @@ extern "C" int mcorb_rig_obtain_lf_features(mcorb_rig *r, int slot, int frame, c
             }
         };
         const int nchunks = (ntracks + kChunk - 1) / kChunk;
-        if (nchunks > 1) R.pool->parallel_for(nchunks, tri_task, R.pool_threads + slot);
-        else if (nchunks == 1) tri_task(0, 0);
+        if (nchunks > 1 && parallel_tri) R.pool->parallel_for(nchunks, tri_task, R.pool_threads + slot);
+        else for (int ch = 0; ch < nchunks; ch++) tri_task(ch, 0);
     }
 
     for (int ind = 0; ind < ntracks; ind++) {                    // (:250-414)
@@ -278,5 +298,68 @@ extern "C" int mcorb_rig_obtain_lf_features(mcorb_rig *r, int slot, int frame, c
     if ((int)intra.size() > cap || (words_fil && (int)wfil.size() > cap_words)) { set_error("obtain_lf_features: output too small"); return MCORB_E_CAP; }
     if (!intra.empty()) memcpy(out, intra.data(), intra.size() * sizeof(mcorb_lf_feature));
     if (words_fil && !wfil.empty()) memcpy(words_fil, wfil.data(), wfil.size() * sizeof(uint32_t));
+    return MCORB_OK;
+}
+
+extern "C" int mcorb_rig_obtain_lf_features(mcorb_rig *r, int slot, int frame, const int32_t *tracks, int ntracks,
+                                            const uint32_t *words, const mcorb_camera *cams, const float *const *seg_masks,
+                                            int seg_stride, const mcorb_keypoint *const *kps_undist, int total_feats,
+                                            mcorb_lf_feature *out, int cap, int *n_out, int *intramatch_size_out,
+                                            int *mono_size_out, uint32_t *words_fil, int cap_words, int *nwords_fil_out)
+{
+    if (n_out) *n_out = 0;
+    if (!r || slot < 0 || slot >= (int)r->rig.slots.size()) { set_error("obtain_lf_features: bad argument"); return MCORB_E_ARG; }
+    Rig &R = r->rig;
+    Slot *s = R.slots[slot];
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        if (s->busy) { set_error("slot busy"); return MCORB_E_STATE; }
+    }
+    return lf_one_frame(R, s, slot, frame, tracks, ntracks, words, cams, seg_masks, seg_stride, kps_undist, total_feats, out, cap, n_out,
+                        intramatch_size_out, mono_size_out, words_fil, cap_words, nwords_fil_out, true);
+}
+
+// All frames [frame0, frame0 + nframes) of a slot in one call, one worker-pool task per frame (the per-frame call is 70 x the
+// 0.03 ms per frame of the extraction that feeds it; FrontEnd.cpp:1024 calls obtainLfFeatures once per frame right after
+// computeIntraMatches).  tracks / words: the frames' arrays back to back, ntracks[f] tracks (ncams ints each) and words per
+// frame; seg_masks / kps_undist: nframes * ncams pointers (index f * ncams + cam) or NULL; out: nframes blocks of `cap` entries,
+// words_fil: nframes blocks of cap_words; the four count arrays have nframes entries.  Returns the first failing frame's status.
+extern "C" int mcorb_rig_obtain_lf_features_frames(mcorb_rig *r, int slot, int frame0, int nframes, const int32_t *tracks,
+                                                   const int32_t *ntracks, const uint32_t *words, const mcorb_camera *cams,
+                                                   const float *const *seg_masks, int seg_stride,
+                                                   const mcorb_keypoint *const *kps_undist, int total_feats, mcorb_lf_feature *out,
+                                                   int cap, int *n_out, int *intramatch_size_out, int *mono_size_out,
+                                                   uint32_t *words_fil, int cap_words, int *nwords_fil_out)
+{
+    if (!r || slot < 0 || slot >= (int)r->rig.slots.size() || nframes < 1 || frame0 < 0 || !ntracks || !n_out || !intramatch_size_out ||
+        !mono_size_out || !out || cap < 0 || (words_fil && !nwords_fil_out)) {
+        set_error("obtain_lf_features_frames: bad argument");
+        return MCORB_E_ARG;
+    }
+    Rig &R = r->rig;
+    Slot *s = R.slots[slot];
+    {
+        std::lock_guard<std::mutex> lk(s->m);
+        if (s->busy) { set_error("slot busy"); return MCORB_E_STATE; }
+    }
+    const int C = R.ncams;
+    std::vector<size_t> off((size_t)nframes + 1, 0);
+    for (int f = 0; f < nframes; f++) {
+        if (ntracks[f] < 0) { set_error("obtain_lf_features_frames: negative track count"); return MCORB_E_ARG; }
+        off[f + 1] = off[f] + (size_t)ntracks[f];
+    }
+    std::vector<int> status((size_t)nframes, MCORB_OK);
+    std::vector<std::string> errs((size_t)nframes);
+    R.pool->parallel_for(nframes, [&](int f, int) {
+        int nw = 0;
+        status[f] = lf_one_frame(R, s, slot, frame0 + f, tracks ? tracks + off[f] * C : nullptr, ntracks[f], words ? words + off[f] : nullptr, cams,
+                                 seg_masks ? seg_masks + (size_t)f * C : nullptr, seg_stride, kps_undist ? kps_undist + (size_t)f * C : nullptr,
+                                 total_feats, out + (size_t)f * cap, cap, &n_out[f], &intramatch_size_out[f], &mono_size_out[f],
+                                 words_fil ? words_fil + (size_t)f * cap_words : nullptr, cap_words, &nw, false);
+        if (nwords_fil_out) nwords_fil_out[f] = nw;
+        if (status[f] != MCORB_OK) errs[f] = get_error();   // (the error text is per thread)
+    }, R.pool_threads + slot);
+    for (int f = 0; f < nframes; f++)
+        if (status[f] != MCORB_OK) { set_error("frame " + std::to_string(frame0 + f) + ": " + errs[f]); return status[f]; }
     return MCORB_OK;
 }

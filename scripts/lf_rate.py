@@ -27,6 +27,17 @@ for rep in range(3):
         feats, n_intra, n_mono, _ = rig.obtain_lf_features(f, tr, Ks, Rs, ts, seg_masks=seg)
         times.append(time.perf_counter() - t0)
         nf, nt = len(feats), len(tr)
+# all frames of the slot in one call (mcorb_rig_obtain_lf_features_frames)
+trs = [rig.tracks(f)[0] for f in range(F)]
+segs = seg * F
+tb = []
+for rep in range(5):
+    t0 = time.perf_counter()
+    res = rig.obtain_lf_features_frames(0, trs, Ks, Rs, ts, seg_masks=segs)
+    tb.append((time.perf_counter() - t0) / F)
 rig.close()
-print(json.dumps({"obtain_lf_features_ms_per_rig_frame": round(float(np.median(times)) * 1e3, 3), "tracks": int(nt), "features": int(nf),
-                  "note": "median of 96 calls through the ctypes binding (includes marshalling the camera matrices and masks)"}))
+print(json.dumps({"obtain_lf_features_ms_per_rig_frame": round(float(np.median(times)) * 1e3, 3),
+                  "obtain_lf_features_frames_ms_per_rig_frame": round(float(np.median(tb)) * 1e3, 4), "frames_per_call": F,
+                  "tracks": int(nt), "features": int(nf),
+                  "note": "single: median of 96 calls through the ctypes binding; frames: %d frames per call, median of 5 calls / %d "
+                          "(both include marshalling the camera matrices, masks and the numpy copies of the results)" % (F, F)}))
