@@ -125,6 +125,12 @@ def main():
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses device 0")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: take the N>1 code path (export -> RCCL all-to-all -> external match) even at N=1")
+    ap.add_argument("--exchange", choices=["a2a", "allgather"], default="a2a",
+                    help="N > 1: a2a = one all-to-all per round, every set goes to the rank that matches its frame (throughput default); "
+                         "allgather = every rank receives every set (what SURVEY 8e / north_star describe), used with --partition pairs")
+    ap.add_argument("--partition", choices=["frames", "pairs"], default="frames",
+                    help="N > 1: frames = frame f matched on rank f mod N; pairs = camera pair (i, j) of frame f matched on rank "
+                         "(i + j + f) mod N, the accepted lists gathered on rank 0, which runs the serial track merge")
     ap.add_argument("--dump-tracks", default=None, help="(tests) write the tracks of this rank's first frames to an .npz")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
@@ -167,7 +173,12 @@ def main():
                 os.dup2(saved, 1)
                 os.close(saved)
 
-    S = args.slots if args.slots else (12 if DIST else 6)
+    PAIRS = DIST and args.partition == "pairs"
+    if (args.exchange == "allgather") != (args.partition == "pairs"):
+        raise SystemExit("supported combinations: --exchange a2a --partition frames (default), --exchange allgather --partition pairs")
+    if PAIRS:
+        os.environ.setdefault("MCORB_BENCH_GROUPS", "1")   # the literal 8(e) path is run round by round, not pipelined
+    S = args.slots if args.slots else ((2 if PAIRS else 12) if DIST else 6)
     G = int(os.environ.get("MCORB_BENCH_GROUPS", "6")) if DIST else 1   # slot groups: with N > 1 G-1 groups extract ahead while one is matched
     IT = 2 if DIST else 1              # exchange rounds per step on the N > 1 path (one round = one group = SG slot jobs per rank)
     if DIST and S % G:
@@ -189,6 +200,8 @@ def main():
     shard = import_module("mc-slam_amd.sharding")
     if not DIST:
         mine = [(f, c) for f in range(F) for c in range(NCAMS)]
+    elif PAIRS:
+        mine = shard.images_of_rank(rank, N, NCAMS, total_frames)
     else:
         mine = shard.a2a_images_of_rank(rank, N, NCAMS, total_frames)
     assert len(mine) == F * NCAMS, (len(mine), F * NCAMS)
@@ -200,7 +213,80 @@ def main():
         rig.upload(imgs, slot=s)
         slot_imgs.append(imgs)
 
-    if DIST:
+    if PAIRS:
+        # ---- SURVEY 8(e) as written: all-gather of {n, desc[K][32]} per camera, pair (i, j) of frame f on rank (i + j + f) mod N,
+        #      the accepted (query, train) tables back to rank 0 for computeIntraMatches' serial merge ----
+        nsets = F * NCAMS
+        IT = 1
+        local_desc = [torch.zeros((nsets, kcap, 32), dtype=torch.uint8, device="cuda")]
+        local_cnt = [torch.zeros(nsets, dtype=torch.int32, device="cuda")]
+        all_desc = torch.zeros((N * nsets, kcap, 32), dtype=torch.uint8, device="cuda")
+        all_cnt = torch.zeros(N * nsets, dtype=torch.int32, device="cuda")
+        batches = shard.pair_batches(rank, N, NCAMS, total_frames, fps)       # jobs of one slot's worth of frames
+        my_pairs = shard.pairs_of_rank(rank, N, NCAMS, total_frames)
+        maxp = max(len(shard.pairs_of_rank(r, N, NCAMS, total_frames)) for r in range(N))
+        table_h = torch.zeros((maxp, 1 + 2 * kcap), dtype=torch.int32).pin_memory()
+        table_d = torch.zeros((maxp, 1 + 2 * kcap), dtype=torch.int32, device="cuda")
+        gathered = [torch.zeros_like(table_d) for _ in range(N)] if rank == 0 else None
+        gidx = shard.gathered_set_index(N, NCAMS, total_frames)
+        my_frames = list(range(total_frames))
+        torch.cuda.synchronize()
+        cstream = torch.cuda.Stream()
+        tstream = cstream.cuda_stream
+        assert tstream != 0
+        exchange_bytes = N * nsets * (kcap * 32 + 4)
+        pairs_result = {}
+
+        def pairs_round(timed=False):
+            for i in range(SG):
+                rig.extract_submit(per_slot, slot=i)
+            for i in range(SG):
+                rig.extract_wait(slot=i)
+                if timed:
+                    account(i)      # (the extraction kernels; the k-NN jobs below overwrite the slot's timing record)
+                rig.export_descriptors_dev(local_desc[0][i * per_slot].data_ptr(), local_cnt[0][i * per_slot:].data_ptr(), per_slot,
+                                           slot=i, then_stream=tstream)
+            with torch.cuda.stream(cstream):
+                dist.all_gather_into_tensor(all_desc, local_desc[0])        # the exchange step (RCCL over xGMI)
+                dist.all_gather_into_tensor(all_cnt, local_cnt[0])
+            k, inflight = 0, {}
+            tab = table_h.numpy()
+            for b, (pairs, psets) in enumerate(batches):
+                slot = b % SG
+                if slot in inflight:
+                    k = collect_pairs(slot, inflight.pop(slot), tab)
+                rig.match_pairs_external_dev_submit(all_desc.data_ptr(), all_cnt.data_ptr(), N * nsets, psets, slot=slot, after_stream=tstream)
+                inflight[slot] = (b, len(pairs))
+            for slot in sorted(inflight, key=lambda s_: inflight[s_][0]):
+                collect_pairs(slot, inflight[slot], tab)
+            table_d.copy_(table_h, non_blocking=True)
+            dist.gather(table_d, gathered, dst=0)                           # the tables return to the rank that merges
+            if rank == 0:
+                counts = all_cnt.cpu().numpy()
+                lists = {}
+                for r_ in range(N):
+                    g_ = gathered[r_].cpu().numpy()
+                    for row, key in zip(g_, shard.pairs_of_rank(r_, N, NCAMS, total_frames)):
+                        n_ = int(row[0])
+                        lists[key] = (row[1:1 + n_].astype(np.uint32), row[1 + kcap:1 + kcap + n_].astype(np.uint32))
+                for f in range(total_frames):
+                    pl = [lists[(f, i, j)] for i in range(NCAMS - 1) for j in range(i + 1, NCAMS)]
+                    pairs_result[f] = mcorb.merge_tracks(NCAMS, [counts[gidx[(f, c)]] for c in range(NCAMS)], pl)
+
+        batch_base = np.cumsum([0] + [len(p) for p, _ in batches])
+
+        def collect_pairs(slot, job, tab):
+            b, npairs = job
+            rig.match_wait(slot=slot)
+            base = int(batch_base[b])
+            for p_ in range(npairs):
+                i1, i2 = rig.pairlist(p_, slot=slot)
+                tab[base + p_, 0] = len(i1)
+                tab[base + p_, 1:1 + len(i1)] = i1
+                tab[base + p_, 1 + kcap:1 + kcap + len(i2)] = i2
+            return base + npairs
+
+    if DIST and not PAIRS:
         nsets = F * NCAMS                                       # sets a rank exports = sets it receives, per step
         send_splits = shard.a2a_send_splits(rank, N, NCAMS, total_frames)
         recv_splits = shard.a2a_recv_splits(rank, N, NCAMS, total_frames)
@@ -293,6 +379,10 @@ def main():
         is collected), so step boundaries do not drain the pipeline; stage(slot), if given, runs in front of every job.
         N > 1: G slot groups rotate; extraction of steps k+1 .. k+G-2 is in flight while step k's descriptors
         are exchanged and matched."""
+        if PAIRS:
+            for _ in range(nsteps):
+                pairs_round(timed)
+            return
         if DIST:
             # step k runs on group k % G.  While step k's descriptors are exchanged, step k-1 is being matched and steps
             # k+1 .. k+G-2 are being extracted; a group is re-armed (next extraction) as soon as its matching is collected.
@@ -367,7 +457,10 @@ def main():
     dts = [timed_region(args.steps, True) for _ in range(max(1, args.repeats))]
     dt = float(np.median(dts))
 
-    if args.dump_tracks:
+    if args.dump_tracks and PAIRS:
+        if rank == 0:
+            np.savez(args.dump_tracks, frames=np.array(list(range(fps))), **{"t%d" % i: pairs_result[i][0] for i in range(fps)})
+    elif args.dump_tracks:
         np.savez(args.dump_tracks, frames=np.array(my_frames[:fps] if DIST else list(range(fps))),
                  **{"t%d" % i: rig.tracks(i, slot=0)[0] for i in range(fps)})
 
@@ -434,7 +527,10 @@ def main():
         "config": {"workload": cfg["label"], "name": args.config,
                    "frames_per_rank_per_step": F * IT, "slots": S, "frames_per_launch": fps, "cameras": NCAMS, "nfeatures": NFEAT,
                    "sharding": "single GPU" if not DIST else
-                   "camera (c+f) mod N for extraction, one RCCL all-to-all of descriptor sets per step (each set goes to rank f mod N only), frame f mod N for matching"},
+                   ("camera (c+f) mod N for extraction, one RCCL all-gather of every camera's {n, desc[K][32]} per round, camera pair (i,j) of frame f "
+                    "matched on rank (i+j+f) mod N, accepted lists gathered on rank 0 for the serial track merge (SURVEY 8e as written; not pipelined)"
+                    if PAIRS else
+                    "camera (c+f) mod N for extraction, one RCCL all-to-all of descriptor sets per step (each set goes to rank f mod N only), frame f mod N for matching")},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
                      "avg_launch_us": round(avg_us, 2), "algorithmic_bytes_per_launch": int(unit_bytes * units),
@@ -477,8 +573,8 @@ def main():
                                    "floor_us": round(floor_us, 1), "frac_in_flight": round(floor_us / avg_us, 3),
                                    "evidence": "profiles/r03_valu_rates.txt (tools/valu_rates.hip, 1/2/4/8 waves per SIMD)"}
     if DIST:
-        out["exchange"] = {"collective": "all_to_all_single (uneven splits)", "bytes_sent_per_rank_per_step": int(exchange_bytes * IT), "rounds_per_step": IT,
-                           "send_splits_rank0": send_splits}
+        out["exchange"] = {"collective": "all_gather_into_tensor + gather of the pair tables to rank 0" if PAIRS else "all_to_all_single (uneven splits)", "bytes_sent_per_rank_per_step": int(exchange_bytes * IT), "rounds_per_step": IT,
+                           "send_splits_rank0": None if PAIRS else send_splits}
     if iso:
         ia = unit_bytes * units / (iso[dominant] * 1e-6) / 1e9
         out["roofline"].update({"isolated_launch_us": round(iso[dominant], 2), "isolated_achieved": round(ia, 2),

@@ -205,6 +205,39 @@ int mcorb_rig_export_descriptors_dev(mcorb_rig *r, int slot, void *dst_dev, int3
 int mcorb_rig_match_external_dev_submit(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts_dev, int ntotal,
                                         const int32_t *sets, int nframes, float dist_thresh, float ratio, void *after_stream);
 
+/* Pair-partitioned matching, the multi-GPU split SURVEY.md 8(e) describes for ONE rig frame across GPUs: every camera's
+ * descriptors are all-gathered, BruteForceMatch of camera pair (i, j) (MultiCameraFrame.cpp:1118 loop, :1024-1086) runs on one
+ * rank, and the accepted (query, train) lists return to the rank that runs computeIntraMatches' serial merge (:1167-1268).
+ * _match_pairs_external*: pair_sets[2p], pair_sets[2p + 1] = query / train set of pair p inside the external block; at most
+ * (images per slot) distinct sets and ncams (ncams - 1) / 2 x (frames per slot) pairs per job; no tracks are built
+ * (mcorb_rig_get_tracks fails), the lists are read with mcorb_rig_get_pairlist (pair = index into pair_sets).  The _dev_submit
+ * form orders the job behind `after_stream` like mcorb_rig_match_external_dev_submit; wait with mcorb_rig_match_wait.
+ * mcorb_host_merge_tracks: the merge itself on caller-supplied lists (pairs in (0,1), (0,2), .., (1,2), .. order, npair[p]
+ * entries each, counts[c] keypoints per camera) -> tracks [n][ncams], -1 = absent; no device involved. */
+int mcorb_rig_match_pairs_external(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts, int ntotal,
+                                   const int32_t *pair_sets, int npairs, float dist_thresh, float ratio);
+int mcorb_rig_match_pairs_external_dev_submit(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts_dev, int ntotal,
+                                              const int32_t *pair_sets, int npairs, float dist_thresh, float ratio, void *after_stream);
+int mcorb_rig_get_pairlist(mcorb_rig *r, int slot, int pair, uint32_t *idx1, uint32_t *idx2, int cap, int *n_out);
+int mcorb_host_merge_tracks(int ncams, const int32_t *counts, const uint32_t *const *idx1, const uint32_t *const *idx2,
+                            const int32_t *npair, int32_t *tracks, int cap_tracks, int *ntracks_out, int *mergeable_out);
+
+/* Device-resident descriptor sets + matching between any two of them (findInterMatches / findMatchesMono call
+ * knnMatch(k = 2) on the LF descriptors of consecutive keyframes, <= 3000 x 3000, ratio 0.7, threshold 50, FrontEnd.cpp:3114-3500).
+ * A block holds nsets sets of up to kcap descriptors in HBM (kcap = mcorb_rig_kcap of the rig that will match them: create that
+ * rig with nfeatures >= the largest set).  Upload a keyframe's descriptors ONCE; the previous keyframe's set stays resident, so an
+ * inter-frame match moves one set over PCIe, not two (mcorb_knn2 re-uploads both).  mcorb_rig_match_sets = BFMatcher knnMatch(k=2)
+ * + the (dist_thresh, ratio) filter of BruteForceMatch on explicit (query set, train set) pairs; read the accepted pairs with
+ * mcorb_rig_get_pairlist and the raw k-NN table (DMatch order: lowest train index first on ties) with mcorb_rig_get_pairknn2. */
+typedef struct mcorb_descblock mcorb_descblock;
+int mcorb_descblock_create(int device, int nsets, int kcap, mcorb_descblock **out);
+void mcorb_descblock_destroy(mcorb_descblock *b);
+int mcorb_descblock_upload(mcorb_descblock *b, int set, const uint8_t *desc, int n);
+void *mcorb_descblock_desc_ptr(mcorb_descblock *b);
+int32_t *mcorb_descblock_counts_dev(mcorb_descblock *b);
+int mcorb_rig_match_sets(mcorb_rig *r, int slot, mcorb_descblock *b, const int32_t *pair_sets, int npairs, float dist_thresh, float ratio);
+int mcorb_rig_get_pairknn2(mcorb_rig *r, int slot, int pair, int32_t *idx, int32_t *dist, int cap_rows, int *nq_out);
+
 /* ------------------------------------------------------------------------- */
 /* Single-camera extractor: ORBextractor (ORBextractor.h:43-116)              */
 /* ------------------------------------------------------------------------- */

@@ -343,6 +343,40 @@ class Rig:
     def match_wait(self, slot=0):
         _lib.check(self.L.mcorb_rig_match_wait(self.h_rig, slot))
 
+    # pair-partitioned matching: explicit (query set, train set) pairs of an external block
+    def match_pairs_external(self, desc_dev_ptr, counts, pair_sets, slot=0, dist_thresh=75.0, ratio=0.85):
+        counts = np.ascontiguousarray(counts, np.int32)
+        pair_sets = np.ascontiguousarray(pair_sets, np.int32).reshape(-1, 2)
+        _lib.check(self.L.mcorb_rig_match_pairs_external(self.h_rig, slot, desc_dev_ptr, counts.ctypes.data, len(counts),
+                                                         pair_sets.ctypes.data, len(pair_sets), dist_thresh, ratio))
+
+    def match_pairs_external_dev_submit(self, desc_dev_ptr, counts_dev_ptr, ntotal, pair_sets, slot=0, dist_thresh=75.0, ratio=0.85,
+                                        after_stream=None):
+        pair_sets = np.ascontiguousarray(pair_sets, np.int32).reshape(-1, 2)
+        self._keep = getattr(self, "_keep", {})
+        self._keep[slot] = (pair_sets,)            # must outlive the asynchronous job
+        _lib.check(self.L.mcorb_rig_match_pairs_external_dev_submit(self.h_rig, slot, desc_dev_ptr, counts_dev_ptr, int(ntotal),
+                                                                    pair_sets.ctypes.data, len(pair_sets), dist_thresh, ratio, after_stream))
+
+    def match_sets(self, block, pair_sets, slot=0, dist_thresh=75.0, ratio=0.85):
+        """knnMatch(k=2) + (dist_thresh, ratio) filter between sets of a DescriptorBlock; read with pairlist / pairknn2"""
+        pair_sets = np.ascontiguousarray(pair_sets, np.int32).reshape(-1, 2)
+        _lib.check(self.L.mcorb_rig_match_sets(self.h_rig, slot, block.h, pair_sets.ctypes.data, len(pair_sets), dist_thresh, ratio))
+
+    def pairknn2(self, pair, slot=0):
+        """raw knnMatch(k=2) table of pair `pair` of the last explicit-pair match -> (idx [nq][2], dist [nq][2]), -1 = absent"""
+        idx, dist = np.zeros((self.kcap, 2), np.int32), np.zeros((self.kcap, 2), np.int32)
+        n = C.c_int()
+        _lib.check(self.L.mcorb_rig_get_pairknn2(self.h_rig, slot, pair, idx.ctypes.data, dist.ctypes.data, self.kcap, C.byref(n)))
+        return idx[:n.value].copy(), dist[:n.value].copy()
+
+    def pairlist(self, pair, slot=0):
+        """accepted (query, train) indices of pair `pair` of the last explicit-pair match -> (idx1, idx2)"""
+        i1, i2 = np.zeros(self.kcap, np.uint32), np.zeros(self.kcap, np.uint32)
+        n = C.c_int()
+        _lib.check(self.L.mcorb_rig_get_pairlist(self.h_rig, slot, pair, i1.ctypes.data, i2.ctypes.data, self.kcap, C.byref(n)))
+        return i1[:n.value].copy(), i2[:n.value].copy()
+
 
 class ORBextractor:
     """Mirror of the reference's ORBextractor (ORBextractor.h:43-116) over libmcorb."""
@@ -586,6 +620,52 @@ class ORBVocabulary:
         """transform() of image m's descriptors straight from the rig's HBM buffers (MultiCameraFrame.cpp:257)."""
         n = rig.L.mcorb_rig_num_keypoints(rig.h_rig, slot, m)
         return self._call(self.L_.mcorb_rig_transform_image, (rig.h_rig, slot, m, self.h), max(n, 0), levelsup)
+
+
+class DescriptorBlock:
+    """nsets descriptor sets resident in HBM (mcorb_descblock): upload a keyframe's LF descriptors once, match any two sets with
+    Rig.match_sets (findInterMatches' knnMatch, FrontEnd.cpp:3344-3500)."""
+
+    def __init__(self, nsets, kcap, device=0):
+        self.L = _lib.load()
+        self.h = C.c_void_p()
+        _lib.check(self.L.mcorb_descblock_create(device, nsets, kcap, C.byref(self.h)))
+        self.nsets, self.kcap = nsets, kcap
+
+    def upload(self, set_index, desc):
+        d = _u8(desc).reshape(-1, 32)
+        _lib.check(self.L.mcorb_descblock_upload(self.h, set_index, d.ctypes.data, len(d)))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mcorb_descblock_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def merge_tracks(ncams, counts, pair_lists):
+    """computeIntraMatches' serial track merge (MultiCameraFrame.cpp:1167-1268) on host arrays, no device: counts[c] keypoints
+    per camera, pair_lists[p] = (idx1, idx2) of camera pair p in (0,1), (0,2), .., (1,2), .. order -> (tracks [n][ncams], mergeable)."""
+    L = _lib.load()
+    counts = np.ascontiguousarray(counts, np.int32)
+    npairs = ncams * (ncams - 1) // 2
+    assert len(pair_lists) == npairs and len(counts) == ncams
+    keep = [(np.ascontiguousarray(a, np.uint32), np.ascontiguousarray(b, np.uint32)) for a, b in pair_lists]
+    p1, p2 = (C.c_void_p * npairs)(), (C.c_void_p * npairs)()
+    for p, (a, b) in enumerate(keep):
+        assert len(a) == len(b)
+        p1[p], p2[p] = a.ctypes.data, b.ctypes.data
+    npair = np.array([len(a) for a, _ in keep], np.int32)
+    cap = int(npair.sum()) + 1
+    tr = np.full((cap, ncams), -1, np.int32)
+    n, mg = C.c_int(), C.c_int()
+    _lib.check(L.mcorb_host_merge_tracks(ncams, counts.ctypes.data, p1, p2, npair.ctypes.data, tr.ctypes.data, cap, C.byref(n), C.byref(mg)))
+    return tr[:n.value].copy(), mg.value
 
 
 def fundamental_from_extrinsics(K_i, R_i, t_i, K_j, R_j, t_j):

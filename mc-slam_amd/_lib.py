@@ -75,6 +75,17 @@ SIGNATURES = {
     "mcorb_rig_get_blurred": (_i, [_vp, _i, _i, _i, _vp, _i]),
     "mcorb_rig_get_candidates": (_i, [_vp, _i, _i, _i, _vp, _i, _ip]),
     "mcorb_rig_last_timing": (_i, [_vp, _i, C.POINTER(_f)]),
+    "mcorb_rig_match_pairs_external": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _f, _f]),
+    "mcorb_rig_match_pairs_external_dev_submit": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _f, _f, _vp]),
+    "mcorb_rig_get_pairlist": (_i, [_vp, _i, _i, _vp, _vp, _i, _ip]),
+    "mcorb_host_merge_tracks": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _ip, _ip]),
+    "mcorb_descblock_create": (_i, [_i, _i, _i, _vp]),
+    "mcorb_descblock_destroy": (None, [_vp]),
+    "mcorb_descblock_upload": (_i, [_vp, _i, _vp, _i]),
+    "mcorb_descblock_desc_ptr": (_vp, [_vp]),
+    "mcorb_descblock_counts_dev": (_vp, [_vp]),
+    "mcorb_rig_match_sets": (_i, [_vp, _i, _vp, _vp, _i, _f, _f]),
+    "mcorb_rig_get_pairknn2": (_i, [_vp, _i, _i, _vp, _vp, _i, _ip]),
     "mcorb_rig_kcap": (_i, [_vp]),
     "mcorb_rig_host_threads": (_i, [_vp]),
     "mcorb_rig_info": (_i, [_vp, _vp]),

@@ -439,6 +439,154 @@ int mcorb_rig_match_external_dev_submit(mcorb_rig *r, int slot, const void *desc
     return r->rig.submit(slot, j);
 }
 
+// ---- pair-partitioned matching (pair (i, j) of a frame on one GPU, the tables back to one rank for the merge) ----
+int mcorb_rig_match_pairs_external_dev_submit(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts_dev, int ntotal,
+                                              const int32_t *pair_sets, int npairs, float dist_thresh, float ratio, void *after_stream)
+{
+    if (!r || !desc_dev || !counts_dev || !pair_sets) { set_error("null argument"); return MCORB_E_ARG; }
+    Job j;
+    j.kind = Job::MATCH; j.nframes = 0; j.dist_thresh = dist_thresh; j.ratio = ratio;
+    j.ext_desc = desc_dev; j.ext_counts_dev = counts_dev; j.ext_total = ntotal; j.ext_pairs = pair_sets; j.ext_npairs = npairs;
+    j.after_stream = (hipStream_t)after_stream;
+    if (after_stream) {
+        Slot *s = get_slot(r, slot);
+        if (!s) return MCORB_E_STATE;
+        HIPCHK(hipSetDevice(r->rig.device));
+        HIPCHK(hipEventRecord(s->ev_x, (hipStream_t)after_stream));
+    }
+    return r->rig.submit(slot, j);
+}
+
+int mcorb_rig_match_pairs_external(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts, int ntotal,
+                                   const int32_t *pair_sets, int npairs, float dist_thresh, float ratio)
+{
+    if (!r || !desc_dev || !counts || !pair_sets) { set_error("null argument"); return MCORB_E_ARG; }
+    Job j;
+    j.kind = Job::MATCH; j.nframes = 0; j.dist_thresh = dist_thresh; j.ratio = ratio;
+    j.ext_desc = desc_dev; j.ext_counts = counts; j.ext_total = ntotal; j.ext_pairs = pair_sets; j.ext_npairs = npairs;
+    const int st = r->rig.submit(slot, j);
+    return st != MCORB_OK ? st : r->rig.wait(slot);
+}
+
+int mcorb_rig_get_pairlist(mcorb_rig *r, int slot, int pair, uint32_t *idx1, uint32_t *idx2, int cap, int *n_out)
+{
+    if (n_out) *n_out = 0;
+    Slot *s = get_slot(r, slot);
+    if (!s) return MCORB_E_STATE;
+    if (pair < 0 || pair >= s->npairs_done) { set_error("bad pair index"); return MCORB_E_ARG; }
+    const int n = (int)s->m_idx1[pair].size();
+    if (n_out) *n_out = n;
+    if (n > cap || (n && (!idx1 || !idx2))) { set_error("pair list: output too small"); return MCORB_E_CAP; }
+    if (n) {
+        memcpy(idx1, s->m_idx1[pair].data(), (size_t)n * sizeof(uint32_t));
+        memcpy(idx2, s->m_idx2[pair].data(), (size_t)n * sizeof(uint32_t));
+    }
+    return MCORB_OK;
+}
+
+// ---- device-resident descriptor sets (N1: findInterMatches' knnMatch between the LF descriptors of consecutive keyframes,
+//      FrontEnd.cpp:3344-3500: the previous keyframe's set stays in HBM, only the new one is uploaded) ----
+struct mcorb_descblock {
+    int device = 0, nsets = 0, kcap = 0;
+    uint8_t *d_desc = nullptr;
+    int32_t *d_counts = nullptr;
+    std::vector<int32_t> h_counts;
+};
+
+int mcorb_descblock_create(int device, int nsets, int kcap, mcorb_descblock **out)
+{
+    if (out) *out = nullptr;
+    if (!out || nsets < 1 || kcap < 64 || (kcap & 63)) { set_error("descblock: kcap must be a positive multiple of 64"); return MCORB_E_ARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) { set_error("no such device"); return MCORB_E_NODEVICE; }
+    HIPCHK(hipSetDevice(device));
+    mcorb_descblock *b = new mcorb_descblock;
+    b->device = device; b->nsets = nsets; b->kcap = kcap;
+    b->h_counts.assign(nsets, 0);
+    if (hipMalloc((void **)&b->d_desc, (size_t)nsets * kcap * 32) != hipSuccess || hipMalloc((void **)&b->d_counts, (size_t)nsets * sizeof(int32_t)) != hipSuccess ||
+        hipMemset(b->d_counts, 0, (size_t)nsets * sizeof(int32_t)) != hipSuccess) {
+        (void)hipFree(b->d_desc); (void)hipFree(b->d_counts);
+        delete b;
+        set_error("descblock: out of device memory");
+        return MCORB_E_HIP;
+    }
+    *out = b;
+    return MCORB_OK;
+}
+
+void mcorb_descblock_destroy(mcorb_descblock *b)
+{
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    (void)hipFree(b->d_desc); (void)hipFree(b->d_counts);
+    delete b;
+}
+
+int mcorb_descblock_upload(mcorb_descblock *b, int set, const uint8_t *desc, int n)
+{
+    if (!b || set < 0 || set >= b->nsets || n < 0 || n > b->kcap || (n && !desc)) { set_error("descblock upload: bad argument"); return MCORB_E_ARG; }
+    HIPCHK(hipSetDevice(b->device));
+    if (n) HIPCHK(hipMemcpy(b->d_desc + (size_t)set * b->kcap * 32, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    const int32_t c = n;
+    HIPCHK(hipMemcpy(b->d_counts + set, &c, sizeof(c), hipMemcpyHostToDevice));
+    b->h_counts[set] = n;
+    return MCORB_OK;
+}
+
+void *mcorb_descblock_desc_ptr(mcorb_descblock *b) { return b ? b->d_desc : nullptr; }
+int32_t *mcorb_descblock_counts_dev(mcorb_descblock *b) { return b ? b->d_counts : nullptr; }
+
+int mcorb_rig_match_sets(mcorb_rig *r, int slot, mcorb_descblock *b, const int32_t *pair_sets, int npairs, float dist_thresh, float ratio)
+{
+    if (!r || !b || !pair_sets) { set_error("null argument"); return MCORB_E_ARG; }
+    if (b->device != r->rig.device || b->kcap != r->rig.geom.kcap) { set_error("match_sets: the block's device / kcap differ from the rig's (mcorb_rig_kcap)"); return MCORB_E_ARG; }
+    return mcorb_rig_match_pairs_external(r, slot, b->d_desc, b->h_counts.data(), b->nsets, pair_sets, npairs, dist_thresh, ratio);
+}
+
+int mcorb_rig_get_pairknn2(mcorb_rig *r, int slot, int pair, int32_t *idx, int32_t *dist, int cap_rows, int *nq_out)
+{
+    if (nq_out) *nq_out = 0;
+    Slot *s = get_slot(r, slot);
+    if (!s) return MCORB_E_STATE;
+    if (pair < 0 || pair >= s->npairs_done || s->nframes_done != 0) { set_error("bad pair index (explicit-pair matches only)"); return MCORB_E_ARG; }
+    const int nq = s->match_counts[s->h_pairs[pair].x];
+    if (nq_out) *nq_out = nq;
+    if (nq > cap_rows || (nq && (!idx || !dist))) { set_error("knn buffer too small"); return MCORB_E_CAP; }
+    std::vector<KnnRow> rows((size_t)std::max(nq, 1));
+    HIPCHK(hipSetDevice(r->rig.device));
+    if (nq) HIPCHK(hipMemcpy(rows.data(), s->d_knn + (size_t)pair * r->rig.geom.kcap, (size_t)nq * sizeof(KnnRow), hipMemcpyDeviceToHost));
+    decode_rows(rows.data(), nq, idx, dist);
+    return MCORB_OK;
+}
+
+// computeIntraMatches' serial track merge on caller-supplied pair lists (no device): what rank 0 runs on the gathered tables
+int mcorb_host_merge_tracks(int ncams, const int32_t *counts, const uint32_t *const *idx1, const uint32_t *const *idx2,
+                            const int32_t *npair, int32_t *tracks, int cap_tracks, int *ntracks_out, int *mergeable_out)
+{
+    if (ntracks_out) *ntracks_out = 0;
+    if (mergeable_out) *mergeable_out = 0;
+    if (ncams < 2 || ncams > MCORB_MAX_CAMS || !counts || !idx1 || !idx2 || !npair) { set_error("merge_tracks: bad argument"); return MCORB_E_ARG; }
+    const int npairs = ncams * (ncams - 1) / 2;
+    int pl = 0;
+    for (int a = 0; a < ncams - 1; a++)
+        for (int b = a + 1; b < ncams; b++, pl++) {
+            if (npair[pl] < 0 || (npair[pl] && (!idx1[pl] || !idx2[pl]))) { set_error("merge_tracks: bad pair list"); return MCORB_E_ARG; }
+            for (int k = 0; k < npair[pl]; k++)
+                if ((int)idx1[pl][k] >= counts[a] || (int)idx2[pl][k] >= counts[b]) { set_error("merge_tracks: index beyond the camera's keypoint count"); return MCORB_E_ARG; }
+        }
+    (void)npairs;
+    std::vector<int32_t> tr;
+    int mergeable = 0;
+    std::vector<int> cnt(counts, counts + ncams), np(npair, npair + pl);
+    merge_pair_lists(ncams, cnt.data(), idx1, idx2, np.data(), nullptr, tr, mergeable);
+    const int n = (int)(tr.size() / ncams);
+    if (ntracks_out) *ntracks_out = n;
+    if (mergeable_out) *mergeable_out = mergeable;
+    if (n > cap_tracks || (n && !tracks)) { set_error("merge_tracks: output too small"); return MCORB_E_CAP; }
+    if (n) memcpy(tracks, tr.data(), tr.size() * sizeof(int32_t));
+    return MCORB_OK;
+}
+
 int mcorb_rig_export_descriptors_dev(mcorb_rig *r, int slot, void *dst_dev, int32_t *counts_dev, int nimg, void *then_stream)
 {
     Slot *s = get_slot(r, slot);

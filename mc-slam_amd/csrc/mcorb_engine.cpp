@@ -948,6 +948,39 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
 int Rig::prepare_match(Slot &s, const Job &j)
 {
     const bool ext = j.ext_desc != nullptr;
+    if (j.ext_pairs) {
+        // explicit (query set, train set) pairs of an external block: local set i = the i-th distinct set the list names
+        if (!ext || j.ext_npairs < 1 || j.ext_npairs > max_pairs() || j.ext_total < 1 || j.ext_total > ext_cap || (!j.ext_counts && !j.ext_counts_dev)) {
+            set_error("match pairs: bad external block or pair count (at most " + std::to_string(max_pairs()) + " pairs per job)");
+            return MCORB_E_ARG;
+        }
+        s.match_external = true;
+        s.match_sets.clear();
+        s.match_counts.clear();
+        std::vector<int> local(j.ext_total, -1);
+        if (j.ext_counts)
+            for (int i = 0; i < j.ext_total; i++) s.h_extcounts[i] = std::min(std::max(j.ext_counts[i], 0), geom.kcap);
+        for (int p = 0; p < j.ext_npairs; p++) {
+            int lp[2];
+            for (int k = 0; k < 2; k++) {
+                const int set = j.ext_pairs[2 * p + k];
+                if (set < 0 || set >= j.ext_total) { set_error("match pairs: set index out of range"); return MCORB_E_ARG; }
+                if (local[set] < 0) {
+                    if ((int)s.match_sets.size() >= max_images) { set_error("match pairs: more than " + std::to_string(max_images) + " distinct sets in one job"); return MCORB_E_ARG; }
+                    local[set] = (int)s.match_sets.size();
+                    s.h_setmap[local[set]] = set;
+                    s.match_sets.push_back(set);
+                    s.match_counts.push_back(j.ext_counts ? s.h_extcounts[set] : 0);
+                }
+                lp[k] = local[set];
+            }
+            s.h_pairs[p] = int2{lp[0], lp[1]};
+        }
+        s.nsets_local = (int)s.match_sets.size();
+        s.npairs_done = j.ext_npairs;
+        s.nframes_done = 0;
+        return MCORB_OK;
+    }
     if (j.nframes < 1 || j.nframes > max_frames || (!ext && j.nframes * ncams > s.nimg_done)) {
         set_error("match: bad frame count or features not extracted");
         return MCORB_E_STATE;
@@ -973,6 +1006,7 @@ int Rig::prepare_match(Slot &s, const Job &j)
         for (int i = 0; i < j.nframes * C; i++) { s.match_sets[i] = i; s.match_counts[i] = s.h_nsel[i]; }
     }
     s.nframes_done = j.nframes;
+    s.nsets_local = j.nframes * C;
     // the k-NN works on LOCAL set indices (frame * cameras + camera): k_expand gathers set setmap[i] into local slot i
     for (int i = 0; i < j.nframes * C; i++) s.h_setmap[i] = s.match_sets[i];
     int p = 0;
@@ -998,7 +1032,7 @@ int Rig::enqueue_match(Slot &s, const Job &j, bool ctrl_on_device)
     if (s.npairs_done == 0) return MCORB_OK;
     const bool ext = j.ext_desc != nullptr;
     HIPCHK(hipEventRecord(s.ev[7], s.st));
-    launch_knn2(s.st, ext ? (const uint8_t *)j.ext_desc : s.d_desc, ext ? s.d_extcounts : s.d_nsel, s.d_setmap, s.nframes_done * ncams,
+    launch_knn2(s.st, ext ? (const uint8_t *)j.ext_desc : s.d_desc, ext ? s.d_extcounts : s.d_nsel, s.d_setmap, s.nsets_local,
                 s.d_pairs, s.npairs_done, geom.kcap, s.d_exp, s.d_lcounts, s.d_part, j.dist_thresh, j.ratio, s.d_knn, s.h_mlist,
                 s.h_mcount, s.ev_e, s.ev[8]);
     HIPCHK(hipEventRecord(s.ev[9], s.st));
@@ -1025,20 +1059,20 @@ static bool epipolar_ok(const double *F, const mcorb_keypoint &k1, const mcorb_k
     return dsqr < check_thresh;
 }
 
-// computeIntraMatches' track merge over the stored BruteForceMatch lists of one frame
+// computeIntraMatches' track merge over the BruteForceMatch lists of one frame
 // (MultiCameraFrame.cpp:1167-1268); gate != nullptr adds the old=true epipolar check.
-void Rig::merge_tracks(Slot &s, int f, const EpipolarGate *gate, std::vector<int32_t> &tr, int &mergeable_out) const
+void merge_pair_lists(int C, const int *counts, const uint32_t *const *idx1, const uint32_t *const *idx2, const int *np,
+                             const EpipolarGate *gate, std::vector<int32_t> &tr, int &mergeable_out)
 {
-    const int C = ncams;
     tr.clear();
     int ntr = 0, mergeable = 0;
     std::vector<std::vector<int>> inv(C);
-    for (int c = 0; c < C; c++) inv[c].assign(s.match_counts[f * C + c], -1);
-    int pi = f * npp, pl = 0;
+    for (int c = 0; c < C; c++) inv[c].assign(std::max(counts[c], 0), -1);
+    int pl = 0;
     for (int a = 0; a < C - 1; a++) {
-        for (int b = a + 1; b < C; b++, pi++, pl++) {
-            const std::vector<uint32_t> &i1 = s.m_idx1[pi], &i2 = s.m_idx2[pi];
-            for (size_t k = 0; k < i1.size(); k++) {
+        for (int b = a + 1; b < C; b++, pl++) {
+            const uint32_t *i1 = idx1[pl], *i2 = idx2[pl];
+            for (int k = 0; k < np[pl]; k++) {
                 const int fa = (int)i1[k], fb = (int)i2[k];
                 const int ma = inv[a][fa], mb = inv[b][fb];
                 if (gate && !epipolar_ok(gate->F + 9 * pl, gate->kps[a][fa], gate->kps[b][fb], gate->sigma2)) continue;
@@ -1070,6 +1104,19 @@ void Rig::merge_tracks(Slot &s, int f, const EpipolarGate *gate, std::vector<int
     mergeable_out = mergeable;
 }
 
+void Rig::merge_tracks(Slot &s, int f, const EpipolarGate *gate, std::vector<int32_t> &tr, int &mergeable_out) const
+{
+    const int C = ncams;
+    const uint32_t *i1[MCORB_MAX_CAMS * MCORB_MAX_CAMS], *i2[MCORB_MAX_CAMS * MCORB_MAX_CAMS];
+    int np[MCORB_MAX_CAMS * MCORB_MAX_CAMS];
+    for (int p = 0; p < npp; p++) {
+        i1[p] = s.m_idx1[f * npp + p].data();
+        i2[p] = s.m_idx2[f * npp + p].data();
+        np[p] = (int)s.m_idx1[f * npp + p].size();
+    }
+    merge_pair_lists(C, &s.match_counts[(size_t)f * C], i1, i2, np, gate, tr, mergeable_out);
+}
+
 // BruteForceMatch's output lists (MultiCameraFrame.cpp:1060-1078) + the track merge, host side,
 // after the k-NN tables landed.
 int Rig::finish_match(Slot &s, const Job &j)
@@ -1092,7 +1139,8 @@ int Rig::finish_match(Slot &s, const Job &j)
         merge_tracks(s, f, nullptr, s.tracks[f], s.mergeable[f]);
     };
     // frames are independent (own pair lists, own track table): one pool task each
-    if (s.nframes_done > 1) pool->parallel_for(s.nframes_done, one_frame, pool_threads + s.index);
+    if (j.ext_pairs) pool->parallel_for(s.npairs_done, filter_pair, pool_threads + s.index);   // explicit pairs: lists only, the merge is the caller's
+    else if (s.nframes_done > 1) pool->parallel_for(s.nframes_done, one_frame, pool_threads + s.index);
     else if (s.nframes_done == 1) one_frame(0, 0);   // (spreading one frame's pairs over the pool was slower: wake-ups)
     if (s.npairs_done > 0) {
         float m = 0;

@@ -83,9 +83,21 @@ struct Job {
     // memory, and the slot's stream first waits for everything enqueued so far on `after_stream` (the collective)
     const int32_t *ext_counts_dev = nullptr;
     hipStream_t after_stream = nullptr;
+    // explicit pair list instead of "all camera pairs of nframes frames" (the pair-partitioned multi-GPU path: pair (i, j) of a
+    // frame is matched on one rank): ext_npairs pairs of (query set, train set) indices into the external block; no
+    // track merge on this rank (nframes = 0), the per-pair lists are read with mcorb_rig_get_pairlist
+    const int32_t *ext_pairs = nullptr;
+    int ext_npairs = 0;
 };
 
 class Rig;
+
+// computeIntraMatches' track merge (MultiCameraFrame.cpp:1167-1268) over the BruteForceMatch lists of one frame's camera pairs
+// in (0,1), (0,2), .., (1,2), .. order: counts[c] keypoints per camera, idx1[p] / idx2[p] the accepted (query, train) indices of
+// pair p (np[p] of them).  gate != nullptr adds the old=true epipolar check.  Shared by the engine and mcorb_host_merge_tracks.
+struct EpipolarGate;
+void merge_pair_lists(int ncams, const int *counts, const uint32_t *const *idx1, const uint32_t *const *idx2, const int *np,
+                      const EpipolarGate *gate, std::vector<int32_t> &tr, int &mergeable_out);
 
 // computeIntraMatches(matches, words_) of one frame (mcorb_rig_match_bow_frames): tracks (ncams ints each), their n_rays, words_
 struct BowFrameOut {
@@ -150,6 +162,7 @@ struct Slot {
     std::vector<int> mono;
     std::vector<std::vector<uint32_t>> sel_val;     // per (image, level): retained candidates (packed), result order
     int npairs_done = 0, nframes_done = 0, nimg_done = 0;
+    int nsets_local = 0;   // descriptor sets the last match expanded (frames x cameras, or the distinct sets of an explicit pair list)
     std::vector<std::vector<uint32_t>> m_idx1, m_idx2;   // per pair
     std::vector<std::vector<int32_t>> tracks;            // per frame, ncams ints per track
     std::vector<int> mergeable;
@@ -218,6 +231,7 @@ public:
     std::vector<SelectScratch *> scratch;   // one per worker
 
     void merge_tracks(Slot &s, int f, const EpipolarGate *gate, std::vector<int32_t> &tr, int &mergeable_out) const;
+    int max_pairs() const { return std::max(1, npp * max_frames); }
 
 private:
     bool copy_kernel = false;  // D2H of tables / descriptors by k_copy_to_host instead of hipMemcpyAsync (see Rig::init)

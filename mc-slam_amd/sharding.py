@@ -87,3 +87,35 @@ def a2a_match_sets(rank, world, ncams, total_frames):
         base += len(part)
     fr = frames_of_rank(rank, world, total_frames)
     return fr, np.array([[idx[(f, c)] for c in range(ncams)] for f in fr], np.int32).reshape(len(fr), ncams)
+
+
+# ---- all-gather + pair partition: the split SURVEY.md 8(e) describes for one rig frame across GPUs ----
+# Every rank holds every set after the all-gather (gathered_set_index); BruteForceMatch of camera pair (i, j) of frame f runs on
+# rank (i + j + f) mod world -- 8(e)'s (i + j) mod G, rotated with the frame so that the six pairs of a 4-camera frame, which
+# never divide evenly, even out over consecutive frames -- and the accepted (query, train) lists go to rank 0, which runs
+# computeIntraMatches' serial merge (MultiCameraFrame.cpp:1167-1268).
+def pair_owner(i, j, f, world):
+    return (i + j + f) % world
+
+
+def pairs_of_rank(rank, world, ncams, total_frames):
+    """(frame, i, j), i < j, matched on `rank`, in (frame, i, j) order"""
+    return [(f, i, j) for f in range(total_frames) for i in range(ncams - 1) for j in range(i + 1, ncams) if pair_owner(i, j, f, world) == rank]
+
+
+def pair_batches(rank, world, ncams, total_frames, frames_per_batch):
+    """the rank's pairs cut into jobs of `frames_per_batch` consecutive frames (a job may name at most one slot's worth of
+    distinct sets): list of (pairs [(f, i, j)], int32 [npairs][2] of gathered set indices)"""
+    idx = gathered_set_index(world, ncams, total_frames)
+    mine = pairs_of_rank(rank, world, ncams, total_frames)
+    out = []
+    for f0 in range(0, total_frames, frames_per_batch):
+        part = [p for p in mine if f0 <= p[0] < f0 + frames_per_batch]
+        if part:
+            out.append((part, np.array([[idx[(f, i)], idx[(f, j)]] for f, i, j in part], np.int32).reshape(len(part), 2)))
+    return out
+
+
+def pair_slot(ncams, i, j):
+    """index of camera pair (i, j), i < j, in (0,1), (0,2), .., (1,2), .. order"""
+    return i * ncams - i * (i + 1) // 2 + (j - i - 1)

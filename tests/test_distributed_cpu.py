@@ -92,14 +92,71 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,worker", [(2, "allgather"), (2, "a2a")])
+def _worker_pairs(rank, world, port, q):
+    """SURVEY 8(e) / north_star as written: one all-gather of every camera's descriptors, camera PAIR (i, j) of a frame matched on
+    one rank (bench.py --exchange allgather --partition pairs), the accepted lists gathered on rank 0, which runs the serial
+    merge.  The oracle's BruteForceMatch stands in for the GPU k-NN; the merge is the product's host function."""
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+    import torch
+    import torch.distributed as dist
+    import oracle_lib as O
+    pkg = import_module("mc-slam_amd")
+    shard = import_module("mc-slam_amd.sharding")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total = FRAMES_PER_RANK * world
+    mine = shard.images_of_rank(rank, world, NCAMS, total)
+    per = shard.sets_per_rank(world, NCAMS, total)
+    local = torch.zeros((per, KCAP, 32), dtype=torch.uint8)
+    cnt = torch.zeros(per, dtype=torch.int32)
+    for i, (f, c) in enumerate(mine):
+        d = _extract(f, c)
+        local[i, :len(d)] = torch.from_numpy(d)
+        cnt[i] = len(d)
+    all_desc = [torch.zeros_like(local) for _ in range(world)]
+    all_cnt = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(all_desc, local)                 # the exchange step: {n, desc[K][32]} of every camera to every rank
+    dist.all_gather(all_cnt, cnt)
+    block, counts = torch.cat(all_desc).numpy(), torch.cat(all_cnt).numpy()
+    # this rank's pairs, in jobs of FRAMES_PER_RANK frames (what one engine slot takes)
+    maxp = max(len(shard.pairs_of_rank(r, world, NCAMS, total)) for r in range(world))
+    table = torch.zeros((maxp, 1 + 2 * KCAP), dtype=torch.int32)    # per pair: n, idx1[n], idx2[n]
+    k = 0
+    for pairs, psets in shard.pair_batches(rank, world, NCAMS, total, FRAMES_PER_RANK):
+        for (f, i, j), (sa, sb) in zip(pairs, psets):
+            i1, i2 = O.bruteforce_match(block[sa, :counts[sa]], block[sb, :counts[sb]])
+            table[k, 0] = len(i1)
+            table[k, 1:1 + len(i1)] = torch.from_numpy(i1.astype(np.int32))
+            table[k, 1 + KCAP:1 + KCAP + len(i2)] = torch.from_numpy(i2.astype(np.int32))
+            k += 1
+    gathered = [torch.zeros_like(table) for _ in range(world)] if rank == 0 else None
+    dist.gather(table, gathered, dst=0)              # the tables return to the rank that merges
+    out = {}
+    if rank == 0:
+        idx = shard.gathered_set_index(world, NCAMS, total)
+        lists = {}
+        for r in range(world):
+            for row, (f, i, j) in zip(gathered[r].numpy(), shard.pairs_of_rank(r, world, NCAMS, total)):
+                n = int(row[0])
+                lists[(f, i, j)] = (row[1:1 + n].astype(np.uint32), row[1 + KCAP:1 + KCAP + n].astype(np.uint32))
+        for f in range(total):
+            pl = [lists[(f, i, j)] for i in range(NCAMS - 1) for j in range(i + 1, NCAMS)]
+            out[f] = pkg.merge_tracks(NCAMS, [counts[idx[(f, c)]] for c in range(NCAMS)], pl)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,worker", [(2, "allgather"), (2, "a2a"), (2, "pairs")])
 def test_sharded_pipeline_equals_single_process(world, worker):
     import torch.multiprocessing as mp
     import oracle_lib as O
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (7 if worker == "a2a" else 0)
-    procs = [ctx.Process(target=_worker if worker == "allgather" else _worker_a2a, args=(r, world, port, q)) for r in range(world)]
+    port = 29500 + (os.getpid() % 2000) + {"allgather": 0, "a2a": 7, "pairs": 13}[worker]
+    target = {"allgather": _worker, "a2a": _worker_a2a, "pairs": _worker_pairs}[worker]
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}
@@ -160,3 +217,29 @@ def test_all_to_all_placement(world, ncams, fpr):
             block += [fc for fc in shard.a2a_images_of_rank(src, world, ncams, total) if shard.dest(fc[0], world) == r]
         for f, row in zip(frames, sets):
             assert [block[i] for i in row] == [(f, c) for c in range(ncams)]
+
+
+@pytest.mark.parametrize("world,ncams,fpr", [(1, 4, 8), (2, 4, 8), (4, 4, 8), (8, 4, 8), (8, 8, 4), (3, 5, 3)])
+def test_pair_partition_placement(world, ncams, fpr):
+    """every camera pair of every frame is matched on exactly one rank; the jobs a rank cuts its pairs into name at most one
+    slot's worth of distinct sets; with the rotation by frame the load is even whenever a round holds a multiple of `world` frames"""
+    shard = import_module("mc-slam_amd.sharding")
+    total = fpr * world
+    allp = []
+    for r in range(world):
+        mine = shard.pairs_of_rank(r, world, ncams, total)
+        assert all(shard.pair_owner(i, j, f, world) == r and i < j for f, i, j in mine)
+        allp += mine
+        idx = shard.gathered_set_index(world, ncams, total)
+        seen = []
+        for pairs, psets in shard.pair_batches(r, world, ncams, total, fpr):
+            assert psets.shape == (len(pairs), 2) and len(set(psets.ravel().tolist())) <= fpr * ncams
+            assert len(pairs) <= fpr * ncams * (ncams - 1) // 2
+            for (f, i, j), (a, b) in zip(pairs, psets):
+                assert (a, b) == (idx[(f, i)], idx[(f, j)])
+            seen += pairs
+        assert seen == mine
+    assert sorted(allp) == [(f, i, j) for f in range(total) for i in range(ncams - 1) for j in range(i + 1, ncams)]
+    per = [len(shard.pairs_of_rank(r, world, ncams, total)) for r in range(world)]
+    assert max(per) - min(per) <= 0 if total % world == 0 else True
+    assert [shard.pair_slot(ncams, i, j) for i in range(ncams - 1) for j in range(i + 1, ncams)] == list(range(ncams * (ncams - 1) // 2))

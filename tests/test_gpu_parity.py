@@ -545,3 +545,71 @@ def test_bench_sharded_path_in_a_fresh_process(tmp_path):
     assert np.array_equal(td["frames"], tf["frames"])
     for i in range(len(tf["frames"])):
         assert np.array_equal(td["t%d" % i], tf["t%d" % i]), "tracks of frame %d differ between the sharded and the fused path" % i
+
+
+def test_bench_pair_partitioned_path_in_a_fresh_process(tmp_path):
+    """bench.py --exchange allgather --partition pairs (SURVEY 8e as written: one RCCL all-gather of every camera's
+    descriptors, camera pair (i, j) of a frame matched by its own job, the accepted lists gathered on rank 0, serial merge
+    there), in a child process at world size 1: the tracks rank 0 assembles equal the fused single-GPU path's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29673", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    outs = {}
+    for name, extra in (("pairs", ["--force-dist", "--exchange", "allgather", "--partition", "pairs", "--slots", "2"]), ("fused", ["--slots", "1"])):
+        dump = str(tmp_path / (name + ".npz"))
+        cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--repeats", "1", "--min-region-s", "0", "--frames", "8",
+               "--host-cores", "0", "--no-cpu", "--no-latency", "--no-staging", "--iso-jobs", "1", "--dump-tracks", dump] + extra
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        outs[name] = (json.loads(line), np.load(dump))
+    jp, tp = outs["pairs"]
+    jf, tf = outs["fused"]
+    assert jp["n_gpus"] == 1 and "all-gather" in jp["config"]["sharding"] and jp["value"] > 0
+    n = len(tp["frames"])
+    assert n >= 4 and np.array_equal(tp["frames"], tf["frames"][:n])
+    for i in range(n):
+        assert len(tf["t%d" % i]) > 100
+        assert np.array_equal(tp["t%d" % i], tf["t%d" % i]), "tracks of frame %d differ between the pair-partitioned and the fused path" % i
+
+
+def test_match_sets_device_resident_interframe_knn():
+    """SURVEY 8f N1 (findInterMatches' knnMatch between the LF descriptors of consecutive keyframes, <= 3000 x 3000, ratio 0.7,
+    threshold 50, FrontEnd.cpp:3344-3500) with the sets resident in HBM: a ring of two sets, one upload per keyframe; k-NN table
+    and accepted pairs equal the oracle's for every consecutive pair, including sets of different sizes and an empty one."""
+    import mcorb
+    rng = np.random.default_rng(21)
+    rig = mcorb.Rig(2, 640, 480, 1, 1, nfeatures=3000)
+    assert rig.kcap >= 3000
+    blk = mcorb.DescriptorBlock(2, rig.kcap)
+    base = rng.integers(0, 256, (3000, 32), dtype=np.uint8)
+
+    def keyframe(k, n):
+        d = base[:n].copy()
+        flip = rng.random((n, 32)) < 0.08 + 0.02 * k       # consecutive keyframes share most bits: real matches, many near ties
+        d[flip] ^= rng.integers(1, 256, (n, 32), dtype=np.uint8)[flip]
+        return rng.permutation(d)
+    sizes = [3000, 2871, 3000, 0, 1500, 3000]
+    prev = keyframe(0, sizes[0])
+    blk.upload(0, prev)
+    for k in range(1, len(sizes)):
+        cur = keyframe(k, sizes[k])
+        blk.upload(k % 2, cur)                               # the previous keyframe's set stays where it is
+        rig.match_sets(blk, [[(k - 1) % 2, k % 2]], dist_thresh=50.0, ratio=0.7)
+        gi, gd = rig.pairknn2(0)
+        g1, g2 = rig.pairlist(0)
+        if len(prev) == 0:
+            assert len(gi) == 0 and len(g1) == 0
+        else:
+            oi, od = O.knn2(prev, cur) if len(cur) else (np.full((len(prev), 2), -1, np.int32), np.full((len(prev), 2), -1, np.int32))
+            assert np.array_equal(gi, oi) and np.array_equal(gd, od), "knn table, keyframe %d" % k
+            if len(cur) >= 2:
+                o1, o2 = O.bruteforce_match(prev, cur, 50.0, 0.7)
+                assert np.array_equal(g1, o1) and np.array_equal(g2, o2) and (k != 1 or len(o1) > 500)
+            else:
+                assert len(g1) == 0
+        prev = cur
+    blk.close()
+    rig.close()
