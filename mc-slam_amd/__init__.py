@@ -329,11 +329,15 @@ class Rig:
     def export_descriptors_dev(self, dst_dev_ptr, counts_dev_ptr, nimg, slot=0, then_stream=None):
         """Stream-ordered export: sets + int32 counts into caller device memory; `then_stream` (raw HIP stream handle)
         waits for the copies."""
+        if then_stream:
+            _lib.require_torch_first("export_descriptors_dev")
         _lib.check(self.L.mcorb_rig_export_descriptors_dev(self.h_rig, slot, dst_dev_ptr, counts_dev_ptr, nimg, then_stream))
 
     def match_external_dev_submit(self, desc_dev_ptr, counts_dev_ptr, ntotal, sets, slot=0, dist_thresh=75.0, ratio=0.85,
                                   after_stream=None):
         """External match with device-resident counts; the slot's stream waits for `after_stream` (the collective)."""
+        if after_stream:
+            _lib.require_torch_first("match_external_dev_submit")
         sets = np.ascontiguousarray(sets, np.int32).reshape(-1, self.ncams)
         self._keep = getattr(self, "_keep", {})
         self._keep[slot] = (sets,)                 # must outlive the asynchronous job
@@ -352,6 +356,8 @@ class Rig:
 
     def match_pairs_external_dev_submit(self, desc_dev_ptr, counts_dev_ptr, ntotal, pair_sets, slot=0, dist_thresh=75.0, ratio=0.85,
                                         after_stream=None):
+        if after_stream:
+            _lib.require_torch_first("match_pairs_external_dev_submit")
         pair_sets = np.ascontiguousarray(pair_sets, np.int32).reshape(-1, 2)
         self._keep = getattr(self, "_keep", {})
         self._keep[slot] = (pair_sets,)            # must outlive the asynchronous job

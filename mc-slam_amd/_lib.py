@@ -6,6 +6,7 @@ and if no gfx950 device is usable the C calls return MCORB_E_NODEVICE.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -128,13 +129,26 @@ SIGNATURES = {
 }
 
 _lib = None
+LOADED_BEFORE_TORCH = False   # libmcorb.so (and with it /opt/rocm's HIP runtime) entered the process before torch did
+
+
+def require_torch_first(what):
+    """The stream-ordered multi-GPU calls exchange device pointers and HIP stream handles with torch (tensors of the collective,
+    torch.cuda.Stream().cuda_stream).  That only works when both sides use ONE HIP runtime, which is the case when torch -- which
+    ships its own libamdhip64 -- is imported BEFORE libmcorb.so is loaded: libmcorb then binds to the runtime
+    already in the process.  The other order gives two runtimes whose handles mean nothing to each other; instead of letting
+    that surface as a hang or an 'invalid resource handle' three calls later, refuse here."""
+    if LOADED_BEFORE_TORCH and "torch" in sys.modules:
+        raise RuntimeError("mc-slam_amd: %s was called with a torch-owned stream / tensor, but libmcorb.so was loaded before torch was "
+                           "imported in this process: `import torch` first, then `import mcorb` (INTEGRATION.md section 5)" % what)
 
 
 def load():
     """Load libmcorb.so; raises if it has not been built (no fallback path exists)."""
-    global _lib
+    global _lib, LOADED_BEFORE_TORCH
     if _lib is not None:
         return _lib
+    LOADED_BEFORE_TORCH = "torch" not in sys.modules
     if not os.path.exists(LIB_PATH):
         raise ImportError("libmcorb.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
                           "g.build()'` or `make -C mc-slam_amd/csrc` (hipcc, gfx950). There is no CPU fallback."

@@ -464,8 +464,7 @@ int mcorb_rig_match_pairs_external(mcorb_rig *r, int slot, const void *desc_dev,
     Job j;
     j.kind = Job::MATCH; j.nframes = 0; j.dist_thresh = dist_thresh; j.ratio = ratio;
     j.ext_desc = desc_dev; j.ext_counts = counts; j.ext_total = ntotal; j.ext_pairs = pair_sets; j.ext_npairs = npairs;
-    const int st = r->rig.submit(slot, j);
-    return st != MCORB_OK ? st : r->rig.wait(slot);
+    return r->rig.run_sync(slot, j);   // on the calling thread: no hand-off to the slot's driver and back
 }
 
 int mcorb_rig_get_pairlist(mcorb_rig *r, int slot, int pair, uint32_t *idx1, uint32_t *idx2, int cap, int *n_out)
@@ -526,10 +525,11 @@ int mcorb_descblock_upload(mcorb_descblock *b, int set, const uint8_t *desc, int
 {
     if (!b || set < 0 || set >= b->nsets || n < 0 || n > b->kcap || (n && !desc)) { set_error("descblock upload: bad argument"); return MCORB_E_ARG; }
     HIPCHK(hipSetDevice(b->device));
-    if (n) HIPCHK(hipMemcpy(b->d_desc + (size_t)set * b->kcap * 32, desc, (size_t)n * 32, hipMemcpyHostToDevice));
-    const int32_t c = n;
-    HIPCHK(hipMemcpy(b->d_counts + set, &c, sizeof(c), hipMemcpyHostToDevice));
     b->h_counts[set] = n;
+    // (the count first, asynchronously from the block's own array; the blocking copy behind it on the same stream covers both)
+    HIPCHK(hipMemcpyAsync(b->d_counts + set, &b->h_counts[set], sizeof(int32_t), hipMemcpyHostToDevice, nullptr));
+    if (n) HIPCHK(hipMemcpy(b->d_desc + (size_t)set * b->kcap * 32, desc, (size_t)n * 32, hipMemcpyHostToDevice));
+    else HIPCHK(hipStreamSynchronize(nullptr));
     return MCORB_OK;
 }
 
@@ -594,7 +594,7 @@ int mcorb_rig_export_descriptors_dev(mcorb_rig *r, int slot, void *dst_dev, int3
     if (!dst_dev || !counts_dev || nimg < 1 || nimg > s->nimg_done) { set_error("export: bad argument"); return MCORB_E_ARG; }
     HIPCHK(hipSetDevice(r->rig.device));
     HIPCHK(hipMemcpyAsync(dst_dev, s->d_desc, (size_t)nimg * r->rig.geom.kcap * 32, hipMemcpyDeviceToDevice, s->st));
-    HIPCHK(hipMemcpyAsync(counts_dev, s->d_nsel, (size_t)nimg * sizeof(int), hipMemcpyDeviceToDevice, s->st));
+    HIPCHK(hipMemcpyAsync(counts_dev, s->h_nsel, (size_t)nimg * sizeof(int), hipMemcpyHostToDevice, s->st));   // (pinned; the device mirror is not filled for small batches)
     if (then_stream) {   // whatever the caller enqueues on then_stream next (the collective) runs after the two copies
         HIPCHK(hipEventRecord(s->ev_x, s->st));
         HIPCHK(hipStreamWaitEvent((hipStream_t)then_stream, s->ev_x, 0));
@@ -810,9 +810,8 @@ static int knn2_host_arrays(mcorb_t *e, const uint8_t *q, int nq, const uint8_t 
     const int need = (std::max(std::max(nq, nt), 1) + 63) / 64 * 64;
     if (need > e->kc) {
         free_knn_scratch(e);
-        const int nchunks = (need + kKnnChunk - 1) / kKnnChunk;
         HIPCHK(hipMalloc((void **)&e->d_desc, (size_t)2 * need * 32));
-        HIPCHK(hipMalloc((void **)&e->d_part, (size_t)nchunks * need * sizeof(uint2)));
+        HIPCHK(hipMalloc((void **)&e->d_part, knn_part_entries(1, need) * sizeof(uint2)));
         HIPCHK(hipMalloc((void **)&e->d_exp, (size_t)2 * need * kKnnExpandBytes));
         HIPCHK(hipMalloc((void **)&e->d_lcounts, 2 * sizeof(int)));
         HIPCHK(hipHostMalloc((void **)&e->h_rows, (size_t)need * sizeof(KnnRow), hipHostMallocMapped));

@@ -475,7 +475,6 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     for (int i = 0; i < nthreads + nslots; i++) scratch.push_back(new SelectScratch);   // workers, then one per slot's submitting thread
 
     const int npairs_max = std::max(1, npp * max_frames);
-    const int nchunks = (geom.kcap + kKnnChunk - 1) / kKnnChunk;
     // an external block usually holds the sets of all slots of a rank (all-to-all) or of all ranks (all-gather)
     ext_cap = (int)align_up(std::max((size_t)4096, (size_t)64 * max_images), 64);
     for (int si = 0; si < nslots; si++) {
@@ -515,7 +514,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         TRY(dev_alloc(&s->d_desc, M * geom.kcap * 32));
         HIPCHK(hipMemset(s->d_desc, 0, M * geom.kcap * 32));
         TRY(dev_alloc(&s->d_angles, M * geom.kcap));
-        TRY(dev_alloc(&s->d_part, (size_t)npairs_max * nchunks * geom.kcap));
+        TRY(dev_alloc(&s->d_part, knn_part_entries(npairs_max, geom.kcap)));
         TRY(dev_alloc(&s->d_exp, M * geom.kcap * (size_t)kKnnExpandBytes));
         TRY(dev_alloc(&s->d_lcounts, M));
         TRY(host_alloc(&s->h_cand, M * geom.hostCandCap));
@@ -599,6 +598,8 @@ Rig::~Rig()
 
 // An upload into a slot whose job is still running would overwrite the staging buffer and level 0 between the job's
 // GPU phases (the slot's stream is idle while the host selects): refuse it like every other call on a busy slot.
+constexpr int kSmallBatch = 8;   // images: at most two 4-camera rig frames
+
 static bool slot_busy(Slot &s)
 {
     std::lock_guard<std::mutex> lk(s.m);
@@ -785,6 +786,11 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
 {
     if (j.nimg < 1 || j.nimg > max_images) { set_error("extract: bad image count"); return MCORB_E_ARG; }
     s.invalidate_bow();   // tracks / BoW vectors of the previous batch index keypoints that are about to disappear
+    // A single rig frame (how MC-SLAM calls, mc_slam_app.cpp:564-572) is launch- and hand-off-bound: ~25 runtime calls and three
+    // small copies around 250 us of kernels.  For small batches the three copies go: k_compact writes its tables straight into the
+    // host-mapped h_tbl, the describe / k-NN kernels read the control block from host-mapped h_ctrl, k_describe_fused writes the
+    // host's descriptor copy itself (a few hundred KB over PCIe in all).
+    s.small_job = j.nimg <= kSmallBatch && params.orientation == 0 && !blur_planes;
     s.h_overflow[0] = 0;
     HIPCHK(hipEventRecord(s.ev[0], s.st));
     launch_pyramid(s.st, s.d_pyr, geom, d_taps, resize_win, j.nimg);
@@ -795,8 +801,15 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
     // of whatever comes next); the DMA that takes the blocks to the host runs on the side stream.
     static const bool side = getenv("MCORB_COMPACT_SIDE") != nullptr;   // round-1 placement, for comparison
     if (side) HIPCHK(hipStreamWaitEvent(s.st_copy, s.ev[2], 0));
-    launch_compact(side ? s.st_copy : s.st, s.d_cellkp, s.d_cellcnt, geom, d_lut, s.d_sorted, s.h_cand, s.d_tbl, s.h_overflow, j.nimg);
+    launch_compact(side ? s.st_copy : s.st, s.d_cellkp, s.d_cellcnt, geom, d_lut, s.d_sorted, s.h_cand, s.small_job ? s.h_tbl : s.d_tbl, s.h_overflow, j.nimg);
     HIPCHK(hipEventRecord(s.ev_c, side ? s.st_copy : s.st));
+    if (s.small_job && !side) {
+        HIPCHK(hipEventRecord(s.ev[3], s.st));   // the tables are in host memory when k_compact is done
+        s.blur_valid = false;
+        HIPCHK(hipEventRecord(s.ev[4], s.st));
+        HIPCHK(hipGetLastError());
+        return MCORB_OK;
+    }
     if (!side) HIPCHK(hipStreamWaitEvent(s.st_copy, s.ev_c, 0));
     if (!copy_kernel) HIPCHK(hipMemcpyAsync(s.h_tbl, s.d_tbl, (size_t)j.nimg * s.tbl_ints_per_image * sizeof(int), hipMemcpyDeviceToHost, s.st_copy));
     else launch_copy_to_host(s.st_copy, s.d_tbl, s.h_tbl, (size_t)j.nimg * s.tbl_ints_per_image * sizeof(int));
@@ -904,6 +917,28 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
 
     s.nimg_done = nimg;
     if (then_match) TRY(prepare_match(s, j));
+    if (s.small_job) {
+        // no copies: the kernels read the control block from the host-mapped h_ctrl and k_describe_fused writes h_desc itself
+        HIPCHK(hipEventRecord(s.ev[5], s.st));
+        launch_describe(s.st, s.d_pyr, nullptr, geom, s.h_sel, s.h_nsel, 0, s.d_desc, s.d_angles, nimg, s.h_desc);
+        HIPCHK(hipEventRecord(s.ev[6], s.st));
+        if (then_match) TRY(enqueue_match(s, j, true));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(s.ev[10], s.st));
+        HIPCHK(wait_event(s.ev[10]));
+        s.nimg_done = nimg;
+        float a = 0, c = 0, t = 0;
+        (void)hipEventElapsedTime(&a, s.ev[0], s.ev[2]);
+        (void)hipEventElapsedTime(&c, s.ev[5], s.ev[6]);
+        s.timing[0] = a * 1000.f;
+        s.timing[2] = c * 1000.f;
+        s.timing[8] = 0.f;
+        s.timing[9] = c * 1000.f;
+        (void)hipEventElapsedTime(&t, s.ev[0], s.ev[1]); s.timing[4] = t * 1000.f;
+        (void)hipEventElapsedTime(&t, s.ev[1], s.ev[2]); s.timing[5] = t * 1000.f;
+        (void)hipEventElapsedTime(&t, s.ev[2], s.ev_c); s.timing[6] = t * 1000.f;
+        return MCORB_OK;
+    }
     // one H2D copy of the control block: counts, pair list, packed selected keypoints
     HIPCHK(hipMemcpyAsync(s.d_ctrl, s.h_ctrl, s.ctrl_bytes, hipMemcpyHostToDevice, s.st));
     HIPCHK(hipEventRecord(s.ev[5], s.st));
@@ -1032,8 +1067,9 @@ int Rig::enqueue_match(Slot &s, const Job &j, bool ctrl_on_device)
     if (s.npairs_done == 0) return MCORB_OK;
     const bool ext = j.ext_desc != nullptr;
     HIPCHK(hipEventRecord(s.ev[7], s.st));
-    launch_knn2(s.st, ext ? (const uint8_t *)j.ext_desc : s.d_desc, ext ? s.d_extcounts : s.d_nsel, s.d_setmap, s.nsets_local,
-                s.d_pairs, s.npairs_done, geom.kcap, s.d_exp, s.d_lcounts, s.d_part, j.dist_thresh, j.ratio, s.d_knn, s.h_mlist,
+    const bool hostctrl = ctrl_on_device && s.small_job && !ext;   // (the fused path of a small batch: no H2D copy was made)
+    launch_knn2(s.st, ext ? (const uint8_t *)j.ext_desc : s.d_desc, ext ? s.d_extcounts : (hostctrl ? s.h_nsel : s.d_nsel),
+                hostctrl ? s.h_setmap : s.d_setmap, s.nsets_local, hostctrl ? s.h_pairs : s.d_pairs, s.npairs_done, geom.kcap, s.d_exp, s.d_lcounts, s.d_part, j.dist_thresh, j.ratio, s.d_knn, s.h_mlist,
                 s.h_mcount, s.ev_e, s.ev[8]);
     HIPCHK(hipEventRecord(s.ev[9], s.st));
     HIPCHK(hipGetLastError());

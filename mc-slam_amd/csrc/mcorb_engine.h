@@ -180,6 +180,7 @@ struct Slot {
     float timing[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<int> match_sets, match_counts;   // per (frame, cam) of the last match: set index, descriptor count
     bool match_external = false;
+    bool small_job = false;   // the running job is a small batch: tables, control block and descriptors go through host-mapped memory, no copies
     // driver thread
     std::thread th;
     std::mutex m;

@@ -7,6 +7,22 @@
 namespace mcorb {
 
 constexpr int kKnnChunk = 4096;  // train descriptors per k-NN partial (one workgroup column); the in-chunk index must stay below 8192
+// Chunk length a launch of `npairs` camera pairs uses.  A workgroup walks one chunk of the train set for 256 queries: with the
+// 192 pairs of a 32-frame batch that is 1 536 workgroups of 63 tiles, plenty; the 6 pairs of ONE rig frame (how MC-SLAM calls
+// the front-end) are 48 workgroups on 256 CUs, each walking all 63 tiles: 44 us of a 0.6 ms frame.  Few pairs -> short chunks
+// -> more, shorter workgroups (the partials are merged by k_knn2_finalize either way).  Multiples of 64 (one LDS stage).
+__host__ __device__ inline int knn_chunk_len(int npairs) { return npairs <= 12 ? 256 : npairs <= 24 ? 512 : npairs <= 48 ? 1024 : kKnnChunk; }
+// partials (uint2) a slot needs for jobs of up to max_pairs pairs at capacity kcap
+inline size_t knn_part_entries(int max_pairs, int kcap)
+{
+    size_t need = 0;
+    for (int np : {12, 24, 48, max_pairs}) {
+        const int n = np < max_pairs ? np : max_pairs, cl = knn_chunk_len(n);
+        const size_t e = (size_t)n * ((kcap + cl - 1) / cl) * kcap;
+        need = need > e ? need : e;
+    }
+    return need;
+}
 constexpr int kKnnExpandBytes = 256;   // bytes of one descriptor expanded to +-64 int8 (k_expand)
 
 // one row of the knnMatch(k=2) table, 8 bytes so the PCIe write-back stays small:
@@ -35,10 +51,11 @@ void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt
                     uint32_t *sorted_dev, uint32_t *cand, int *tbl, int *overflow, int nimg);
 void launch_blur(hipStream_t st, const uint8_t *pyr, uint8_t *blur, const Geom &g, int nimg);
 void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, const Geom &g, const uint32_t *sel,
-                     const int *nsel, int orientation, uint8_t *desc, float *angles, int nimg);
+                     const int *nsel, int orientation, uint8_t *desc, float *angles, int nimg,
+                     uint8_t *desc_host = nullptr);   // desc_host (k_describe_fused only): host-mapped second destination
 // desc / counts: `kcap`-strided bit descriptors and their counts; setmap[i] (null = identity) = the set that becomes local
 // set i, i < nsets; pairs: (query, train) LOCAL set indices; expanded: nsets * kcap * kKnnExpandBytes bytes of scratch;
-// lcounts: nsets ints (receives the clamped counts); part: npairs * ceil(kcap / kKnnChunk) * kcap partials
+// lcounts: nsets ints (receives the clamped counts); part: knn_part_entries(max pairs per launch, kcap) partials
 void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const int *setmap, int nsets, const int2 *pairs, int npairs,
                  int kcap, void *expanded, int *lcounts, uint2 *part, float dist_thresh, float ratio, KnnRow *out, uint32_t *mlist,
                  int *mcount, hipEvent_t ev_exp, hipEvent_t ev_mid);   // events (optional): after k_expand, after k_knn2

@@ -1162,7 +1162,7 @@ __device__ __forceinline__ void fd_wave_sync()
 
 __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restrict__ pyr, Geom g,
                                                         const uint32_t *__restrict__ sel, const int *__restrict__ nsel,
-                                                        uint8_t *__restrict__ desc, int groups)
+                                                        uint8_t *__restrict__ desc, int groups, uint8_t *__restrict__ desc_host)
 {
     __shared__ __attribute__((aligned(16))) uint32_t lds[4][kFdWaveDw];
     static_assert(kFdSrcDw % 4 == 0 && kFdHpDw % 4 == 0, "16-byte aligned regions");
@@ -1274,6 +1274,8 @@ __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restric
         if (lane < 4 && k0 + u < n) {
             const unsigned long long b = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
             reinterpret_cast<unsigned long long *>(desc + ((size_t)img * g.kcap + k0 + u) * 32)[lane] = b;
+            // small batches: the host's copy is written here too (host-mapped memory) instead of by a copy behind the kernel
+            if (desc_host) reinterpret_cast<unsigned long long *>(desc_host + ((size_t)img * g.kcap + k0 + u) * 32)[lane] = b;
         }
     }
 #undef FD_FETCH
@@ -1414,7 +1416,7 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c)
 template <int kKnnStageTiles, int kWavesPerSimd>
 __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const uint4 *__restrict__ E, const int *__restrict__ lcounts,
                                                            const int2 *__restrict__ pairs, int kcap, int nchunks, int npairs,
-                                                           int qblocks, uint2 *__restrict__ part)
+                                                           int qblocks, uint2 *__restrict__ part, int chunkLen)
 {
     __shared__ __attribute__((aligned(16))) uint4 stage[2][kKnnStageTiles * kTileU4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
@@ -1426,8 +1428,8 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
     const int nq = lcounts[qt.x], nt = lcounts[qt.y];
     const int qb = (slot - grp * qblocks) * (64 * kKnnWaves);   // first query of the workgroup
     if (qb >= nq) return;
-    const int t0 = chunk * kKnnChunk;
-    const int tn = min(nt - t0, kKnnChunk);             // trains of this chunk
+    const int t0 = chunk * chunkLen;
+    const int tn = min(nt - t0, chunkLen);              // trains of this chunk
     const int tilesPerSet = kcap / 32;
     constexpr int kMin = (int)0x80000000;
     int k0[kKnnQT], k1[kKnnQT];
@@ -1567,7 +1569,7 @@ __device__ __forceinline__ void knn_insert(uint32_t key, uint32_t &k0, uint32_t 
 // flag: m0.distance < ratio * m1.distance && !(m0.distance > dist_thresh)
 // (MultiCameraFrame.cpp:1061-1063), float arithmetic as in the reference.
 __global__ __launch_bounds__(1024) void k_knn2_finalize(const uint2 *__restrict__ part, const int *__restrict__ counts,
-                                                        const int2 *__restrict__ pairs, int kcap, int nchunks,
+                                                        const int2 *__restrict__ pairs, int kcap, int nchunks, int chunkLen,
                                                         float dist_thresh, float ratio, KnnRow *__restrict__ out,
                                                         uint32_t *__restrict__ mlist, int *__restrict__ mcount)
 {
@@ -1578,7 +1580,7 @@ __global__ __launch_bounds__(1024) void k_knn2_finalize(const uint2 *__restrict_
     const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int2 qt = pairs[pair];
     const int nq = min(max(counts[qt.x], 0), kcap), nt = min(max(counts[qt.y], 0), kcap);
-    const int used = (nt + kKnnChunk - 1) / kKnnChunk;
+    const int used = (nt + chunkLen - 1) / chunkLen;
     if (tid == 0) s_run = 0;
     __syncthreads();
     for (int base = 0; base < nq; base += 1024) {
@@ -1827,7 +1829,9 @@ void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt
     const int bktCap = (maxb + 1 + 3) & ~3;
     static const int wg_env = getenv("MCORB_COMPACT_WG") ? atoi(getenv("MCORB_COMPACT_WG")) : 0;
     static const int cells_env = getenv("MCORB_COMPACT_CELLS") ? atoi(getenv("MCORB_COMPACT_CELLS")) : 0;
-    const int wg = wg_env == 1024 || wg_env == 256 ? wg_env : 512, cellsInFlight = cells_env == 4 ? 4 : 8;
+    // 512 threads per (level, image) workgroup is the optimum of a full batch (256: 136 us, 1024: 84-90 us, 512: 72 us per 128
+    // images); a small batch is the latency of its level-0 workgroup, and that one is shorter with 1024 (4 images: 39 vs 57 us)
+    const int wg = wg_env == 1024 || wg_env == 256 || wg_env == 512 ? wg_env : (nimg <= 8 ? 1024 : 512), cellsInFlight = cells_env == 4 ? 4 : 8;
     const int cellsCap = (maxc + 8 + 7) & ~7;   // u16 entries, a multiple of 8
     const size_t lds = (size_t)(3 * bktCap) * sizeof(int) + (size_t)(cellsCap + maxwh + 8) * sizeof(uint16_t);
     const dim3 grid(nimg, g.nlevels);
@@ -1846,7 +1850,7 @@ void launch_blur(hipStream_t st, const uint8_t *pyr, uint8_t *blur, const Geom &
 }
 
 void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, const Geom &g, const uint32_t *sel,
-                     const int *nsel, int orientation, uint8_t *desc, float *angles, int nimg)
+                     const int *nsel, int orientation, uint8_t *desc, float *angles, int nimg, uint8_t *desc_host)
 {
     if (orientation) {
         dim3 grid((g.kcap + 3) / 4, nimg);
@@ -1854,7 +1858,7 @@ void launch_describe(hipStream_t st, const uint8_t *pyr, const uint8_t *blur, co
     } else {
         dim3 grid((g.kcap + 4 * kDescPerWave - 1) / (4 * kDescPerWave), nimg);
         if (blur) hipLaunchKernelGGL(k_describe, grid, dim3(256), 0, st, blur, g, sel, nsel, desc);   // from blurred planes (k_blur ran)
-        else hipLaunchKernelGGL(k_describe_fused, dim3(grid.x * nimg), dim3(256), 0, st, pyr, g, sel, nsel, desc, (int)grid.x);
+        else hipLaunchKernelGGL(k_describe_fused, dim3(grid.x * nimg), dim3(256), 0, st, pyr, g, sel, nsel, desc, (int)grid.x, desc_host);
     }
 }
 
@@ -1865,14 +1869,14 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
     uint4 *E = reinterpret_cast<uint4 *>(expanded);
     hipLaunchKernelGGL(k_expand, dim3((kcap + 255) / 256, nsets), dim3(256), 0, st, desc, counts, setmap, kcap, E, lcounts);
     if (ev_exp) (void)hipEventRecord(ev_exp, st);
-    const int nchunks = (kcap + kKnnChunk - 1) / kKnnChunk;
+    const int chunkLen = knn_chunk_len(npairs), nchunks = (kcap + chunkLen - 1) / chunkLen;
     const int qblocks = (kcap + 64 * kKnnWaves - 1) / (64 * kKnnWaves), units = npairs * nchunks;
     dim3 grid(8 * qblocks * ((units + 7) / 8));
     // 130 VGPRs: 3 waves per SIMD.  (Capping at 128 for 4 waves spills one query fragment into scratch: 177 vs 162 us.)
-    hipLaunchKernelGGL((k_knn2<2, 3>), grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, npairs, qblocks, part);
+    hipLaunchKernelGGL((k_knn2<2, 3>), grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, npairs, qblocks, part, chunkLen);
 
     if (ev_mid) (void)hipEventRecord(ev_mid, st);
-    hipLaunchKernelGGL(k_knn2_finalize, dim3(npairs), dim3(1024), 0, st, part, lcounts, pairs, kcap, nchunks, dist_thresh, ratio, out, mlist,
+    hipLaunchKernelGGL(k_knn2_finalize, dim3(npairs), dim3(1024), 0, st, part, lcounts, pairs, kcap, nchunks, chunkLen, dist_thresh, ratio, out, mlist,
                        mcount);
 }
 

@@ -75,3 +75,18 @@ def test_version_and_error_strings():
     L = _lib.load()
     assert b"gfx950" in L.mcorb_version()
     assert isinstance(L.mcorb_last_error(), bytes)
+
+
+def test_stream_ordered_calls_refuse_a_process_that_loaded_libmcorb_before_torch(monkeypatch):
+    """torch first, then libmcorb -- or two HIP runtimes share the process.  The calls that take torch-owned
+    streams fail loudly instead (mc-slam_amd/_lib.py: require_torch_first)."""
+    import sys
+    import types
+    from importlib import import_module
+    lib = import_module("mc-slam_amd")._lib
+    monkeypatch.setattr(lib, "LOADED_BEFORE_TORCH", True)
+    monkeypatch.setitem(sys.modules, "torch", sys.modules.get("torch") or types.ModuleType("torch"))
+    with pytest.raises(RuntimeError, match="import torch"):
+        lib.require_torch_first("export_descriptors_dev")
+    monkeypatch.setattr(lib, "LOADED_BEFORE_TORCH", False)
+    lib.require_torch_first("export_descriptors_dev")          # the right order: nothing happens
