@@ -946,16 +946,22 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     HIPCHK(hipEventRecord(s.ev[6], s.st));
     // descriptors go back to the host on the side stream (DMA) while the matcher already runs
     static const bool d2h_late = getenv("MCORB_D2H_LATE") != nullptr;   // experiment: copy after the k-NN instead of beside it
-    if (!d2h_late || !then_match) HIPCHK(hipStreamWaitEvent(s.st_dma, s.ev[6], 0));
-    if (then_match && d2h_late) {
+    static const int d2h_mid_env = getenv("MCORB_D2H_AFTER_EXPAND") ? atoi(getenv("MCORB_D2H_AFTER_EXPAND")) : -1;
+    // (experiment, MCORB_D2H_AFTER_EXPAND=1: start the copy behind k_expand.  Whatever kernel of the job ENDS while the copy's
+    // host writes are in flight is held until they have drained -- k_expand 12 -> 148 us beside the copy, k_knn2 154 -> 276 us when
+    // the copy starts behind k_expand, with the runtime's blit and with k_copy_to_host alike (profiles/r03_copy_kernel_ab.txt) --
+    // so the copy stays beside k_expand, whose result nobody needs before k_knn2 anyway: 13.3 k vs 13.0 k frames/s at one slot.)
+    const bool d2h_mid = then_match && !d2h_late && d2h_mid_env > 0;
+    if ((!d2h_late && !d2h_mid) || !then_match) HIPCHK(hipStreamWaitEvent(s.st_dma, s.ev[6], 0));
+    if (then_match && (d2h_late || d2h_mid)) {
         TRY(enqueue_match(s, j, true));
-        HIPCHK(hipStreamWaitEvent(s.st_dma, s.ev[9], 0));
+        HIPCHK(hipStreamWaitEvent(s.st_dma, d2h_mid && s.npairs_done > 0 ? s.ev_e : s.ev[9], 0));
     }
     if (!copy_kernel) HIPCHK(hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)nimg * geom.kcap * 32, hipMemcpyDeviceToHost, s.st_dma));
     else launch_copy_to_host(s.st_dma, s.d_desc, s.h_desc, (size_t)nimg * geom.kcap * 32);
     if (params.orientation)
         HIPCHK(hipMemcpyAsync(s.h_angles, s.d_angles, (size_t)nimg * geom.kcap * sizeof(float), hipMemcpyDeviceToHost, s.st_dma));
-    if (then_match && !d2h_late) TRY(enqueue_match(s, j, true));
+    if (then_match && !d2h_late && !d2h_mid) TRY(enqueue_match(s, j, true));
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(s.ev[10], s.st));
     HIPCHK(hipEventRecord(s.ev[11], s.st_dma));

@@ -21,10 +21,18 @@ echo "traffic done"
 bash scripts/pmc_kernel.sh $O/sq > $O/sq.txt 2>&1 || true
 bash scripts/fetch_calib.sh $O/calib > $O/calib.txt 2>&1 || true
 timeout -k 10 200 python3 scripts/bow_rate.py 2>/dev/null | tail -1 > $O/bow_rate.json || true
+timeout -k 10 200 python3 scripts/lf_rate.py 2>/dev/null | tail -1 > $O/lf_rate.json || true
+timeout -k 10 200 python3 scripts/n1_rate.py 2>/dev/null | tail -1 > $O/n1_rate.json || true
+timeout -k 10 200 python3 scripts/latency.py 2>/dev/null | tail -1 > $O/latency.json || true
+timeout -k 10 200 tools/_build/valu_rates > $O/valu_rates.txt 2>&1 || true
 cp $(find $O/p_def -name '*kernel_stats.csv' | head -1) $O/stats_default.csv
 cp $(find $O/p_1s -name '*kernel_stats.csv' | head -1) $O/stats_1slot.csv
 # the bench line that is kept: run again with traffic.json regenerated from THIS run's counters, so that roofline.traffic and
 # roofline.valu are filled in (bench.py drops them when the kernel sources' sha does not match)
-python3 scripts/install_profiles.py $O ${2:-r02} > /dev/null
+python3 scripts/install_profiles.py $O ${2:-r03} > /dev/null
 timeout -k 10 400 python3 bench.py 2>$O/bench.err | tail -1 > $O/bench_default.json
+# the raw traces stay on the box (gpurun copies back at most 64 MiB): summaries only
+rm -rf $O/p_def $O/p_1s $O/p_f $O/p_w $O/calib $O/sq/p[0-9] $O/sq/p[0-9]/ 2>/dev/null
+find $O -name '*.csv' -size +2M -delete
+du -sh $O
 echo collected into $O
