@@ -815,8 +815,8 @@ static int knn2_host_arrays(mcorb_t *e, const uint8_t *q, int nq, const uint8_t 
         HIPCHK(hipMalloc((void **)&e->d_exp, (size_t)2 * need * kKnnExpandBytes));
         HIPCHK(hipMalloc((void **)&e->d_lcounts, 2 * sizeof(int)));
         HIPCHK(hipHostMalloc((void **)&e->h_rows, (size_t)need * sizeof(KnnRow), hipHostMallocMapped));
-        HIPCHK(hipHostMalloc((void **)&e->h_mlist, (size_t)need * sizeof(uint32_t), hipHostMallocMapped));
-        HIPCHK(hipHostMalloc((void **)&e->h_mcount, sizeof(int), hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void **)&e->h_mlist, knn_mlist_stride(need) * sizeof(uint32_t), hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void **)&e->h_mcount, (size_t)knn_qblocks(need) * sizeof(int), hipHostMallocMapped));
         HIPCHK(hipHostMalloc((void **)&e->h_counts, 2 * sizeof(int), hipHostMallocMapped));
         HIPCHK(hipHostMalloc((void **)&e->h_pair, sizeof(int2), hipHostMallocMapped));
         e->kc = need;

@@ -520,8 +520,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         TRY(host_alloc(&s->h_cand, M * geom.hostCandCap));
         TRY(host_alloc(&s->h_overflow, 16));
         TRY(dev_alloc(&s->d_knn, (size_t)npairs_max * geom.kcap));
-        TRY(host_alloc(&s->h_mlist, (size_t)npairs_max * geom.kcap));
-        TRY(host_alloc(&s->h_mcount, (size_t)npairs_max));
+        TRY(host_alloc(&s->h_mlist, (size_t)npairs_max * knn_mlist_stride(geom.kcap)));
+        TRY(host_alloc(&s->h_mcount, (size_t)npairs_max * knn_qblocks(geom.kcap)));
         {
             const size_t o_nsel = (size_t)ext_cap * sizeof(int);
             const size_t o_setmap = align_up(o_nsel + M * sizeof(int), 64);
@@ -1171,10 +1171,15 @@ int Rig::finish_match(Slot &s, const Job &j)
     auto filter_pair = [&](int pi, int) {   // BruteForceMatch's accept loop for one camera pair (pair index within the job)
         // k_knn2_finalize already compacted the accepted pairs in query order: unpack query << 16 | train
         std::vector<uint32_t> &i1 = s.m_idx1[pi], &i2 = s.m_idx2[pi];
-        const int n = s.h_mcount[pi];
-        const uint32_t *ml = s.h_mlist + (size_t)pi * geom.kcap;
+        const int nqb = knn_qblocks(geom.kcap);
+        const int *cnt = s.h_mcount + (size_t)pi * nqb;
+        const uint32_t *ml = s.h_mlist + (size_t)pi * knn_mlist_stride(geom.kcap);
+        int n = 0;
+        for (int b = 0; b < nqb; b++) n += cnt[b];
         i1.resize(n); i2.resize(n);
-        for (int k = 0; k < n; k++) { i1[k] = ml[k] >> 16; i2[k] = ml[k] & 0xffffu; }
+        int k = 0;
+        for (int b = 0; b < nqb; b++)
+            for (int e = 0; e < cnt[b]; e++, k++) { i1[k] = ml[b * 256 + e] >> 16; i2[k] = ml[b * 256 + e] & 0xffffu; }
     };
     auto one_frame = [&](int f, int w) {
         for (int pi = f * npp; pi < (f + 1) * npp; pi++) filter_pair(pi, w);

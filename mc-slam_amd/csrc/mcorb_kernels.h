@@ -12,6 +12,10 @@ constexpr int kKnnChunk = 4096;  // train descriptors per k-NN partial (one work
 // the front-end) are 48 workgroups on 256 CUs, each walking all 63 tiles: 44 us of a 0.6 ms frame.  Few pairs -> short chunks
 // -> more, shorter workgroups (the partials are merged by k_knn2_finalize either way).  Multiples of 64 (one LDS stage).
 __host__ __device__ inline int knn_chunk_len(int npairs) { return npairs <= 12 ? 256 : npairs <= 24 ? 512 : npairs <= 48 ? 1024 : kKnnChunk; }
+// The accepted (query << 16 | train) pairs of a camera pair come back in blocks of 256 queries: mlist[pair][block * 256 + k],
+// k < mcount[pair * knn_qblocks(kcap) + block]; blocks are in query order (concatenate them).
+inline int knn_qblocks(int kcap) { return (kcap + 255) / 256; }
+inline size_t knn_mlist_stride(int kcap) { return (size_t)knn_qblocks(kcap) * 256; }
 // partials (uint2) a slot needs for jobs of up to max_pairs pairs at capacity kcap
 inline size_t knn_part_entries(int max_pairs, int kcap)
 {

@@ -1413,10 +1413,16 @@ __device__ __forceinline__ int med3_i32(int a, int b, int c)
 // (global_load_lds_dwordx4: no staging registers, which keeps the kernel at 4 waves per SIMD).
 // 1-D grid, XCD-aware: workgroups b and b + 8 share an XCD, so the query blocks of one (pair, chunk) unit are given ids
 // that are congruent mod 8 -- they stream the same train set and find it in their XCD's L2 after the first has fetched it.
-template <int kKnnStageTiles, int kWavesPerSimd>
+// FOLD (launches whose train sets fit one chunk, i.e. every full batch): the kernel finishes the job itself -- k-NN rows, the
+// BruteForceMatch accept test and the accepted pairs compacted per 256-query block (mlist[pair][block * 256 + k], count in
+// mcount[pair * qblocks + block]; blocks are in query order, so the host concatenates them) -- instead of writing partials
+// for k_knn2_finalize: one launch, a 23-us kernel and a partial-table round trip less per batch.
+template <int kKnnStageTiles, int kWavesPerSimd, bool FOLD>
 __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const uint4 *__restrict__ E, const int *__restrict__ lcounts,
                                                            const int2 *__restrict__ pairs, int kcap, int nchunks, int npairs,
-                                                           int qblocks, uint2 *__restrict__ part, int chunkLen)
+                                                           int qblocks, uint2 *__restrict__ part, int chunkLen,
+                                                           float dist_thresh, float ratio, KnnRow *__restrict__ rows,
+                                                           uint32_t *__restrict__ mlist, int *__restrict__ mcount)
 {
     __shared__ __attribute__((aligned(16))) uint4 stage[2][kKnnStageTiles * kTileU4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
@@ -1426,8 +1432,12 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
     const int pair = unit / nchunks, chunk = unit - pair * nchunks;
     const int2 qt = pairs[pair];
     const int nq = lcounts[qt.x], nt = lcounts[qt.y];
-    const int qb = (slot - grp * qblocks) * (64 * kKnnWaves);   // first query of the workgroup
-    if (qb >= nq) return;
+    const int qbi = slot - grp * qblocks;
+    const int qb = qbi * (64 * kKnnWaves);   // first query of the workgroup
+    if (qb >= nq) {
+        if (FOLD && tid == 0) mcount[pair * qblocks + qbi] = 0;
+        return;
+    }
     const int t0 = chunk * chunkLen;
     const int tn = min(nt - t0, chunkLen);              // trains of this chunk
     const int tilesPerSet = kcap / 32;
@@ -1541,21 +1551,63 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
         top2(accA);
     }
     // the two lane halves hold different train rows of the same query columns: merge, convert, store
-    uint2 *out = part + ((size_t)pair * nchunks + chunk) * kcap;
+    auto conv = [&](int key) -> uint32_t {
+        if (key == kMin) return 0xffffffffu;
+        const uint32_t kp = (uint32_t)(key + (1 << 20));            // 8192 * (256 - hamming) + (8191 - index)
+        return ((256u - (kp >> 13)) << 16) | (uint32_t)(t0 + 8191 - (int)(kp & 8191u));
+    };
+    if (!FOLD) {
+        uint2 *out = part + ((size_t)pair * nchunks + chunk) * kcap;
+#pragma unroll
+        for (int u = 0; u < kKnnQT; u++) {
+            const int o0 = __shfl_xor(k0[u], 32), o1 = __shfl_xor(k1[u], 32);
+            const int m0 = max(k0[u], o0), m1 = max(min(k0[u], o0), max(k1[u], o1));
+            const int q = qb + (wave * kKnnQT + u) * 32 + (lane & 31);
+            if (half == 0 && q < nq) out[q] = uint2{conv(m0), conv(m1)};
+        }
+        return;
+    }
+    // folded finalize (k_knn2_finalize's statements on this workgroup's 256 queries): rows, accept flag, compaction in query order
+    int *wcnt = reinterpret_cast<int *>(&stage[0][0]);   // (the stages are idle: every wave is past the loop's last barrier)
+    uint32_t packed[kKnnQT];
+    unsigned long long bal[kKnnQT];
 #pragma unroll
     for (int u = 0; u < kKnnQT; u++) {
         const int o0 = __shfl_xor(k0[u], 32), o1 = __shfl_xor(k1[u], 32);
         const int m0 = max(k0[u], o0), m1 = max(min(k0[u], o0), max(k1[u], o1));
         const int q = qb + (wave * kKnnQT + u) * 32 + (lane & 31);
-        if (half == 0 && q < nq) {
-            auto conv = [&](int key) -> uint32_t {
-                if (key == kMin) return 0xffffffffu;
-                const uint32_t kp = (uint32_t)(key + (1 << 20));            // 8192 * (256 - hamming) + (8191 - index)
-                return ((256u - (kp >> 13)) << 16) | (uint32_t)(t0 + 8191 - (int)(kp & 8191u));
-            };
-            out[q] = uint2{conv(m0), conv(m1)};
+        const uint32_t c0 = conv(m0), c1 = conv(m1);
+        const bool v0 = c0 != 0xffffffffu, v1 = c1 != 0xffffffffu;
+        const uint32_t d0 = v0 ? c0 >> 16 : 0u, d1 = v1 ? c1 >> 16 : 0u, ti0 = c0 & 0xffffu;
+        uint32_t acc = 0;
+        if (v0 && v1) {
+            const float f0 = (float)d0, f1 = (float)d1;   // DMatch::distance is float
+            acc = (f0 < __fmul_rn(ratio, f1)) && !(f0 > dist_thresh);
         }
+        const bool mine = half == 0 && q < nq;
+        if (mine) {
+            KnnRow r;
+            r.idx = (v0 ? ti0 : 0xffffu) | ((v1 ? (c1 & 0xffffu) : 0xffffu) << 16);
+            r.d = d0 | (d1 << 9) | (acc << 18);
+            rows[(size_t)pair * kcap + q] = r;
+        }
+        bal[u] = __ballot(mine && acc != 0);
+        packed[u] = ((uint32_t)q << 16) | ti0;
     }
+    if (lane == 0) {
+#pragma unroll
+        for (int u = 0; u < kKnnQT; u++) wcnt[wave * kKnnQT + u] = __popcll(bal[u]);
+    }
+    __syncthreads();
+    int before = 0;
+    for (int i = 0; i < wave * kKnnQT; i++) before += wcnt[i];
+    uint32_t *ml = mlist + (size_t)pair * (qblocks * 64 * kKnnWaves) + qb;
+#pragma unroll
+    for (int u = 0; u < kKnnQT; u++) {
+        if ((bal[u] >> lane) & 1) ml[lane_rank(bal[u], before)] = packed[u];
+        before += __popcll(bal[u]);
+    }
+    if (wave == kKnnWaves - 1 && lane == 0) mcount[pair * qblocks + qbi] = before;
 }
 
 __device__ __forceinline__ void knn_insert(uint32_t key, uint32_t &k0, uint32_t &k1)
@@ -1571,7 +1623,7 @@ __device__ __forceinline__ void knn_insert(uint32_t key, uint32_t &k0, uint32_t 
 __global__ __launch_bounds__(1024) void k_knn2_finalize(const uint2 *__restrict__ part, const int *__restrict__ counts,
                                                         const int2 *__restrict__ pairs, int kcap, int nchunks, int chunkLen,
                                                         float dist_thresh, float ratio, KnnRow *__restrict__ out,
-                                                        uint32_t *__restrict__ mlist, int *__restrict__ mcount)
+                                                        uint32_t *__restrict__ mlist, int *__restrict__ mcount, int qblocks)
 {
     // One workgroup per camera pair: besides the k-NN rows it emits BruteForceMatch's accepted (query, train) pairs
     // compacted in query order (mlist[pair][k] = query << 16 | train, mcount[pair]), so the host does not scan the rows.
@@ -1610,7 +1662,7 @@ __global__ __launch_bounds__(1024) void k_knn2_finalize(const uint2 *__restrict_
         __syncthreads();
         int before = s_run;
         for (int w = 0; w < wave; w++) before += wsum[w];
-        if (acc) mlist[(size_t)pair * kcap + lane_rank(b, before)] = ((uint32_t)q << 16) | t0;
+        if (acc) mlist[(size_t)pair * (qblocks * 64 * kKnnWaves) + lane_rank(b, before)] = ((uint32_t)q << 16) | t0;
         __syncthreads();
         if (tid == 0) {
             int tot = 0;
@@ -1619,7 +1671,8 @@ __global__ __launch_bounds__(1024) void k_knn2_finalize(const uint2 *__restrict_
         }
         __syncthreads();
     }
-    if (tid == 0) mcount[pair] = s_run;
+    // (same layout as the folded k_knn2 writes -- one count per 256-query block -- with the whole list in block 0)
+    if (tid < qblocks) mcount[pair * qblocks + tid] = tid == 0 ? s_run : 0;
 }
 
 // popcount(x) + acc in one instruction; chaining the eight words of a 256-bit XOR through the
@@ -1873,11 +1926,17 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
     const int qblocks = (kcap + 64 * kKnnWaves - 1) / (64 * kKnnWaves), units = npairs * nchunks;
     dim3 grid(8 * qblocks * ((units + 7) / 8));
     // 130 VGPRs: 3 waves per SIMD.  (Capping at 128 for 4 waves spills one query fragment into scratch: 177 vs 162 us.)
-    hipLaunchKernelGGL((k_knn2<2, 3>), grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, npairs, qblocks, part, chunkLen);
-
+    if (nchunks == 1) {
+        hipLaunchKernelGGL((k_knn2<2, 3, true>), grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, npairs, qblocks, part, chunkLen,
+                           dist_thresh, ratio, out, mlist, mcount);
+        if (ev_mid) (void)hipEventRecord(ev_mid, st);
+        return;
+    }
+    hipLaunchKernelGGL((k_knn2<2, 3, false>), grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, npairs, qblocks, part, chunkLen,
+                       dist_thresh, ratio, out, mlist, mcount);
     if (ev_mid) (void)hipEventRecord(ev_mid, st);
     hipLaunchKernelGGL(k_knn2_finalize, dim3(npairs), dim3(1024), 0, st, part, lcounts, pairs, kcap, nchunks, chunkLen, dist_thresh, ratio, out, mlist,
-                       mcount);
+                       mcount, qblocks);
 }
 
 void launch_bow_best2(hipStream_t st, const uint8_t *desc, int img0, int kcap, int ncams, int nframes, const float *yv,
