@@ -218,8 +218,8 @@ class Rig:
             words = np.ascontiguousarray(words, np.uint32)
             assert len(words) >= len(tracks)
             wp = words.ctypes.data
-        cap = Cn * self.kcap + len(tracks) + 1
-        out = np.zeros(cap, _lib.LF_DTYPE)
+        cap = max(total_feats, len(tracks)) + 1     # intramatch_size <= tracks, and the mono fill stops at total_feats
+        out = np.empty(cap, _lib.LF_DTYPE)
         wf = np.zeros(len(tracks) + 1, np.uint32)
         n, ni, nm, nw = (C.c_int() for _ in range(4))
         _lib.check(self.L.mcorb_rig_obtain_lf_features(self.h_rig, slot, frame, tracks.ctypes.data, len(tracks), wp, cams, segp, stride, undp,
@@ -266,9 +266,9 @@ class Rig:
             words = np.ascontiguousarray(np.concatenate(ws) if nt.sum() else np.zeros(0, np.uint32))
             keep.append(words)
             wp = words.ctypes.data
-        cap = Cn * self.kcap + int(nt.max(initial=0)) + 1
+        cap = max(total_feats, int(nt.max(initial=0))) + 1     # intramatch_size <= tracks, and the mono fill stops at total_feats
         capw = int(nt.max(initial=0)) + 1
-        out = np.zeros((F, cap), _lib.LF_DTYPE)
+        out = np.empty((F, cap), _lib.LF_DTYPE)
         wf = np.zeros((F, capw), np.uint32)
         n, ni, nm, nw = (np.zeros(F, np.int32) for _ in range(4))
         _lib.check(self.L.mcorb_rig_obtain_lf_features_frames(self.h_rig, slot, frame0, F, tracks.ctypes.data, nt.ctypes.data, wp, cams, segp,

@@ -13,9 +13,12 @@
 // full-column-rank-minus-one matrix is unique up to scale, so any stable method returns the same point to ~1e-11 relative;
 // parity for this step is tolerance-based (1e-9) and UNPINNED.
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <functional>
 #include <numeric>
 #include <string>
@@ -30,15 +33,19 @@ namespace {
 // right singular vector of the smallest singular value of the m x n matrix A (row-major, m >= n, n <= 20)
 // = eigenvector of the smallest eigenvalue of G = A^T A, found by inverse iteration: G + delta I is factored ONCE (LU with
 // partial pivoting, n^3 / 3 multiplications), every further step is two triangular solves.  The design matrices of the
-// triangulation have one singular value far below the rest (zero for exact correspondences), so the iteration contracts by
-// lambda_1 / lambda_2 per step -- a handful of steps; grossly wrong correspondences (ratio near 1) take more, the loop runs
-// until two successive iterates agree to 1e-15.  Accuracy: eps |G| / (lambda_2 - lambda_1) on the unit vector, 1e-12 .. 1e-11
+// triangulation have one singular value far below the rest (zero for exact correspondences): unshifted steps until the
+// iterate has settled, then Rayleigh-quotient shifts (a fresh n^3 / 3 factorisation per step, nothing at n = 4 .. 8) until
+// two successive iterates agree to 1e-15.  Accuracy: eps |G| / (lambda_2 - lambda_1) on the unit vector, 1e-12 .. 1e-11
 // for this geometry (the one-sided Jacobi SVD it replaces worked on A itself, eps / sigma_2, at 50 x the cost: 60 sweeps
 // of 6 .. 28 column pairs per track were 10 of the 13 ms a 4-camera frame took in round 2).  The test against LAPACK's SVD
 // (600 cases of 2 .. 6 views, small and gross noise) holds its 1e-9.
 constexpr int kLfMaxN = 4 + MCORB_MAX_CAMS, kLfMaxM = 3 * MCORB_MAX_CAMS;
-void null_vector(const double *A, int m, int n, double *x)
+// M, N > 0: compile-time shape (the 2-, 3- and 4-view designs are almost all the tracks of a 4-camera rig: with the loop
+// bounds known the compiler unrolls and keeps G / LU in registers); M = N = 0: run-time shape
+template <int M, int N>
+inline void null_vector_t(const double *A, int m_rt, int n_rt, double *x)
 {
+    const int m = M > 0 ? M : m_rt, n = N > 0 ? N : n_rt;
     double G[kLfMaxN * kLfMaxN], LU[kLfMaxN * kLfMaxN];
     int piv[kLfMaxN];
     double tr = 0.0;
@@ -50,26 +57,31 @@ void null_vector(const double *A, int m, int n, double *x)
             if (p == q) tr += sacc;
         }
     if (!(tr > 0.0)) { for (int i = 0; i < n; i++) x[i] = i == n - 1 ? 1.0 : 0.0; return; }
-    const double delta = 1e-14 * tr;   // keeps the factorisation away from an exactly singular matrix
-    for (int i = 0; i < n * n; i++) LU[i] = G[i];
-    for (int i = 0; i < n; i++) LU[i * n + i] += delta;
-    for (int k = 0; k < n; k++) {
-        int pk = k;
-        for (int i = k + 1; i < n; i++) if (fabs(LU[i * n + k]) > fabs(LU[pk * n + k])) pk = i;
-        piv[k] = pk;
-        if (pk != k) for (int j = 0; j < n; j++) std::swap(LU[k * n + j], LU[pk * n + j]);
-        double d = LU[k * n + k];
-        if (fabs(d) < 1e-300) { d = d < 0 ? -1e-300 : 1e-300; LU[k * n + k] = d; }
-        const double inv = 1.0 / d;
-        for (int i = k + 1; i < n; i++) {
-            const double f = LU[i * n + k] * inv;
-            LU[i * n + k] = f;
-            if (f != 0.0) for (int j = k + 1; j < n; j++) LU[i * n + j] -= f * LU[k * n + j];
+    const double pivmin = 1e-30 * tr;
+    // factor G - shift I (LU, partial pivoting); a vanishing pivot is nudged: the solve then blows up along the null vector,
+    // which is the point of inverse iteration
+    auto factor = [&](double shift) {
+        for (int i = 0; i < n * n; i++) LU[i] = G[i];
+        for (int i = 0; i < n; i++) LU[i * n + i] -= shift;
+        for (int k = 0; k < n; k++) {
+            int pk = k;
+            for (int i = k + 1; i < n; i++) if (fabs(LU[i * n + k]) > fabs(LU[pk * n + k])) pk = i;
+            piv[k] = pk;
+            if (pk != k) for (int j = 0; j < n; j++) std::swap(LU[k * n + j], LU[pk * n + j]);
+            double d = LU[k * n + k];
+            // (a shift that IS an eigenvalue to the last bit can leave an exactly zero pivot; the nudge must keep the solve
+            // finite -- 1 / 1e-300 squared overflows, and the normalisation then turns the iterate into NaNs)
+            if (fabs(d) < pivmin) { d = d < 0 ? -pivmin : pivmin; LU[k * n + k] = d; }
+            const double inv = 1.0 / d;
+            for (int i = k + 1; i < n; i++) {
+                const double f = LU[i * n + k] * inv;
+                LU[i * n + k] = f;
+                if (f != 0.0) for (int j = k + 1; j < n; j++) LU[i * n + j] -= f * LU[k * n + j];
+            }
         }
-    }
-    double v[kLfMaxN], y[kLfMaxN];
-    for (int i = 0; i < n; i++) v[i] = 1.0 / sqrt((double)n) * (1.0 + 0.01 * i);   // any start with a component along the answer
-    for (int it = 0; it < 400; it++) {
+    };
+    double v[N > 0 ? N : kLfMaxN], y[N > 0 ? N : kLfMaxN];
+    auto solve_step = [&]() -> double {   // v <- normalised (G - shift I)^-1 v, sign kept; returns the largest change of a component
         for (int i = 0; i < n; i++) y[i] = v[i];
         for (int k = 0; k < n; k++)            // P (all row exchanges first: the multipliers sit in their final rows)
             if (piv[k] != k) std::swap(y[k], y[piv[k]]);
@@ -87,9 +99,67 @@ void null_vector(const double *A, int m, int n, double *x)
         const double sgn = dotp < 0 ? -1.0 : 1.0;
         double diff = 0.0;
         for (int i = 0; i < n; i++) { y[i] *= sgn; diff = std::max(diff, fabs(y[i] - v[i])); v[i] = y[i]; }
-        if (it > 0 && diff < 1e-15) break;
+        return diff;
+    };
+    auto rayleigh = [&]() {
+        double r = 0.0;
+        for (int p = 0; p < n; p++) {
+            double gp = 0.0;
+            for (int q = 0; q < n; q++) gp += G[p * n + q] * v[q];
+            r += v[p] * gp;
+        }
+        return r;
+    };
+    for (int i = 0; i < n; i++) v[i] = 1.0 / sqrt((double)n) * (1.0 + 0.01 * i);   // any start with a component along the answer
+    // Unshifted steps -- which can only converge to the eigenvector of the eigenvalue nearest zero, the smallest (G is positive
+    // semi-definite) -- until the iterate has settled to 1e-3; only then Rayleigh-quotient shifts (cubic from there: two or
+    // three steps where the unshifted iteration, contracting by lambda_1 / lambda_2 = 0.1 .. 0.5 on tracks with a wrong
+    // correspondence, needs dozens).  Shifting earlier is not safe: a start vector that happens to be nearly orthogonal to the
+    // answer still has its quotient near lambda_2 after a few steps, and the shifted iteration then converges THERE (seen on 2 %
+    // of real tracks).  Should a shifted step move the iterate by more than 1e-2 it has left the basin: back to unshifted steps.
+    factor(-1e-14 * tr);   // (keeps the factorisation away from an exactly singular matrix)
+    double diff = 1.0;
+    for (int it = 0; it < 400 && diff >= 1e-3; it++) diff = solve_step();
+    bool shifted = false;
+    for (int it = 0; it < 8 && diff >= 1e-15; it++) {
+        factor(rayleigh());
+        diff = solve_step();
+        shifted = true;
+        if (diff > 1e-2) break;
+    }
+    if (shifted) {
+        // "settled" can also mean: sitting next to ANOTHER eigenvector with a tiny component along the wanted one (an unlucky
+        // start); the shifted steps then polish that one.  Sylvester: G - (rho - tol) I has as many negative pivots in its LDL^T
+        // as G has eigenvalues below rho - tol -- none when rho is the smallest.  Otherwise: unshifted iteration to the end.
+        const double rho = rayleigh(), tol = 1e-10 * tr + 1e-3 * fabs(rho);
+        bool smallest = diff <= 1e-2;   // (false for a NaN too)
+        if (smallest) {
+            for (int i = 0; i < n * n; i++) LU[i] = G[i];
+            for (int i = 0; i < n; i++) LU[i * n + i] -= rho - tol;
+            for (int k = 0; k < n && smallest; k++) {
+                const double d = LU[k * n + k];
+                if (!(d > 0.0)) { smallest = false; break; }
+                for (int i = k + 1; i < n; i++) {
+                    const double f = LU[i * n + k] / d;
+                    for (int j = k + 1; j < n; j++) LU[i * n + j] -= f * LU[k * n + j];
+                }
+            }
+        }
+        if (!smallest) {
+            for (int i = 0; i < n; i++) v[i] = 1.0 / sqrt((double)n) * (1.0 + 0.01 * i);
+            factor(-1e-14 * tr);
+            diff = 1.0;
+            for (int k = 0; k < 2000 && diff >= 1e-15; k++) diff = solve_step();
+        }
     }
     for (int i = 0; i < n; i++) x[i] = v[i];
+}
+void null_vector(const double *A, int m, int n, double *x)
+{
+    if (m == 4 && n == 4) null_vector_t<4, 4>(A, m, n, x);
+    else if (m == 9 && n == 7) null_vector_t<9, 7>(A, m, n, x);
+    else if (m == 12 && n == 8) null_vector_t<12, 8>(A, m, n, x);
+    else null_vector_t<0, 0>(A, m, n, x);
 }
 
 // cv::sfm::triangulatePoints for one point seen in nv views: x = normalised image coordinates, P = 3x4 [R|t] (row-major)
@@ -150,6 +220,10 @@ static int lf_one_frame(Rig &R, Slot *s, int slot, int frame, const int32_t *tra
         return MCORB_E_ARG;
     }
     const int C = R.ncams, kcap = R.geom.kcap;
+    static const bool prof = getenv("MCORB_HOST_PROF") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto us = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::micro>(b - a).count(); };
+    const auto T0 = now();
     if (frame < 0 || (frame + 1) * C > s->nimg_done) { set_error("obtain_lf_features: frame not extracted"); return MCORB_E_STATE; }
     const int m0 = frame * C;
     auto KP = [&](int c) -> const std::vector<mcorb_keypoint> & { return s->kps[m0 + c]; };
@@ -169,10 +243,16 @@ static int lf_one_frame(Rig &R, Slot *s, int slot, int frame, const int32_t *tra
     std::vector<const double *> prj(C);
     for (int c = 0; c < C; c++) prj[c] = cams[c].Rt;             // build_Rt(R, t) (:224)
 
-    std::vector<mcorb_lf_feature> intra, mono_keypoints;
+    // mono candidates are kept as (camera, keypoint) only: every one of them becomes the same kind of feature (:396-412 and
+    // :489-512 fill the same fields), and only the best total_feats - intramatch_size are materialised after the sort
+    struct MonoRef { int cam, kp; };
+    std::vector<mcorb_lf_feature> intra;
+    std::vector<MonoRef> mono_keypoints;
     std::vector<float> responses;
     std::vector<uint32_t> wfil;
-    intra.reserve(3000); mono_keypoints.reserve(3000); responses.reserve(3000);
+    size_t nkp_total = 0;
+    for (int c = 0; c < C; c++) nkp_total += KP(c).size();
+    intra.reserve((size_t)std::max(total_feats, ntracks) + 8); mono_keypoints.reserve(nkp_total + 8); responses.reserve(nkp_total + 8);
     int intramatch_size = 0, mono_size = 0;
     auto blank = [&]() {
         mcorb_lf_feature f;
@@ -213,6 +293,7 @@ static int lf_one_frame(Rig &R, Slot *s, int slot, int frame, const int32_t *tra
         else for (int ch = 0; ch < nchunks; ch++) tri_task(ch, 0);
     }
 
+    const auto T1 = now();
     for (int ind = 0; ind < ntracks; ind++) {                    // (:250-414)
         mcorb_lf_feature temp = blank();
         for (int c = 0; c < C; c++) temp.match_index[c] = tracks[(size_t)ind * C + c];
@@ -255,38 +336,38 @@ static int lf_one_frame(Rig &R, Slot *s, int slot, int frame, const int32_t *tra
             }
         } else if (num_views == 1) {                             // (:396-412)
             const int v = view_inds[0], k = temp.match_index[v];
-            memcpy(temp.desc, descs[0], 32);
-            temp.uv_ref[0] = KPU(v, k).x; temp.uv_ref[1] = KPU(v, k).y;
-            temp.n_rays = 1;
-            temp.mono = 1;
-            mono_keypoints.push_back(temp);
+            mono_keypoints.push_back(MonoRef{v, k});
             responses.push_back(KPU(v, k).response);
             keypoint_mask[v][k] = 0;
         }
     }
+    const auto T2 = now();
     // every keypoint no track used becomes a mono candidate, camera by camera (:489-512); the segmentation test is commented
     // out in this branch of the reference
     for (int i = 0; i < C; i++)
         for (int j = 0; j < (int)KP(i).size(); j++)
             if (keypoint_mask[i][j]) {
-                mcorb_lf_feature f = blank();
-                f.match_index[i] = j;
-                memcpy(f.desc, DESC(i, j), 32);
-                f.uv_ref[0] = KPU(i, j).x; f.uv_ref[1] = KPU(i, j).y;
-                f.n_rays = 1;
-                f.mono = 1;
-                mono_keypoints.push_back(f);
+                mono_keypoints.push_back(MonoRef{i, j});
                 responses.push_back(KPU(i, j).response);
                 keypoint_mask[i][j] = 0;
             }
+    const auto T3 = now();
     // argsorte(responses, false) (MCSlam/utils.h:21-30): std::sort of the index sequence, descending response
     std::vector<int> sorted((int)responses.size());
     std::iota(sorted.begin(), sorted.end(), 0);
     std::sort(sorted.begin(), sorted.end(), [&responses](int i, int j) -> bool { return responses[i] > responses[j]; });
     for (int i = 0; i < (int)sorted.size() && i < (total_feats - intramatch_size); ++i) {   // (:515-521)
-        intra.push_back(mono_keypoints[sorted[i]]);
+        const MonoRef &mr = mono_keypoints[sorted[i]];
+        mcorb_lf_feature f = blank();
+        f.match_index[mr.cam] = mr.kp;
+        memcpy(f.desc, DESC(mr.cam, mr.kp), 32);
+        f.uv_ref[0] = KPU(mr.cam, mr.kp).x; f.uv_ref[1] = KPU(mr.cam, mr.kp).y;
+        f.n_rays = 1;
+        f.mono = 1;
+        intra.push_back(f);
         mono_size++;
     }
+    const auto T4 = now();
     // words_fil is a std::set: ascending, unique
     std::sort(wfil.begin(), wfil.end());
     wfil.erase(std::unique(wfil.begin(), wfil.end()), wfil.end());
@@ -298,6 +379,9 @@ static int lf_one_frame(Rig &R, Slot *s, int slot, int frame, const int32_t *tra
     if ((int)intra.size() > cap || (words_fil && (int)wfil.size() > cap_words)) { set_error("obtain_lf_features: output too small"); return MCORB_E_CAP; }
     if (!intra.empty()) memcpy(out, intra.data(), intra.size() * sizeof(mcorb_lf_feature));
     if (words_fil && !wfil.empty()) memcpy(words_fil, wfil.data(), wfil.size() * sizeof(uint32_t));
+    if (prof && frame == 0)
+        fprintf(stderr, "[mcorb host prof] obtain_lf_features frame 0: setup + triangulation %.0f us, track bookkeeping %.0f, mono pool %.0f, sort + fill %.0f, copy out %.0f\n",
+                us(T0, T1), us(T1, T2), us(T2, T3), us(T3, T4), us(T4, now()));
     return MCORB_OK;
 }
 
