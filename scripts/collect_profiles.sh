@@ -7,7 +7,7 @@ O=gpurun_out/${1:-prof}
 mkdir -p $O
 ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd $ROOT
-ONE="--steps 3 --warmup 1 --repeats 1 --no-cpu --no-latency --no-staging --slots 1 --frames 32 --iso-jobs 1"
+ONE="--steps 3 --warmup 1 --repeats 1 --min-region-s 0 --host-cores 0 --no-cpu --no-latency --no-staging --slots 1 --frames 32 --iso-jobs 1"
 timeout -k 10 400 python3 bench.py 2>$O/bench.err | tail -1 > $O/bench_default.json   # provisional (install_profiles.py reads the launch size from it)
 echo "bench done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/p_def -o d -- python3 bench.py --no-cpu --no-latency --no-staging --repeats 1 > $O/p_def.log 2>&1
