@@ -245,27 +245,42 @@ def main():
                 if timed:
                     account(i)      # (the extraction kernels; the k-NN jobs below overwrite the slot's timing record)
                 rig.export_descriptors_dev(local_desc[0][i * per_slot].data_ptr(), local_cnt[0][i * per_slot:].data_ptr(), per_slot,
-                                           slot=i, then_stream=tstream)
-            with torch.cuda.stream(cstream):
-                dist.all_gather_into_tensor(all_desc, local_desc[0])        # the exchange step (RCCL over xGMI)
-                dist.all_gather_into_tensor(all_cnt, local_cnt[0])
+                                           slot=i, then_stream=None if gloo else tstream)
+            if gloo:                                                # rehearsal on a 1-GPU box: the collective on host tensors
+                torch.cuda.synchronize()
+                hd = [torch.zeros(local_desc[0].shape, dtype=torch.uint8) for _ in range(N)]
+                hc = [torch.zeros(local_cnt[0].shape, dtype=torch.int32) for _ in range(N)]
+                dist.all_gather(hd, local_desc[0].cpu())
+                dist.all_gather(hc, local_cnt[0].cpu())
+                all_desc.copy_(torch.cat(hd))
+                all_cnt.copy_(torch.cat(hc))
+                torch.cuda.synchronize()
+            else:
+                with torch.cuda.stream(cstream):
+                    dist.all_gather_into_tensor(all_desc, local_desc[0])    # the exchange step (RCCL over xGMI)
+                    dist.all_gather_into_tensor(all_cnt, local_cnt[0])
             k, inflight = 0, {}
             tab = table_h.numpy()
             for b, (pairs, psets) in enumerate(batches):
                 slot = b % SG
                 if slot in inflight:
                     k = collect_pairs(slot, inflight.pop(slot), tab)
-                rig.match_pairs_external_dev_submit(all_desc.data_ptr(), all_cnt.data_ptr(), N * nsets, psets, slot=slot, after_stream=tstream)
+                rig.match_pairs_external_dev_submit(all_desc.data_ptr(), all_cnt.data_ptr(), N * nsets, psets, slot=slot,
+                                                    after_stream=None if gloo else tstream)
                 inflight[slot] = (b, len(pairs))
             for slot in sorted(inflight, key=lambda s_: inflight[s_][0]):
                 collect_pairs(slot, inflight[slot], tab)
-            table_d.copy_(table_h, non_blocking=True)
-            dist.gather(table_d, gathered, dst=0)                           # the tables return to the rank that merges
+            if gloo:
+                gathered_h = [torch.zeros_like(table_h) for _ in range(N)] if rank == 0 else None
+                dist.gather(table_h, gathered_h, dst=0)
+            else:
+                table_d.copy_(table_h, non_blocking=True)
+                dist.gather(table_d, gathered, dst=0)                       # the tables return to the rank that merges
             if rank == 0:
                 counts = all_cnt.cpu().numpy()
                 lists = {}
                 for r_ in range(N):
-                    g_ = gathered[r_].cpu().numpy()
+                    g_ = (gathered_h[r_] if gloo else gathered[r_].cpu()).numpy()
                     for row, key in zip(g_, shard.pairs_of_rank(r_, N, NCAMS, total_frames)):
                         n_ = int(row[0])
                         lists[key] = (row[1:1 + n_].astype(np.uint32), row[1 + kcap:1 + kcap + n_].astype(np.uint32))
@@ -461,6 +476,8 @@ def main():
         if rank == 0:
             np.savez(args.dump_tracks, frames=np.array(list(range(fps))), **{"t%d" % i: pairs_result[i][0] for i in range(fps)})
     elif args.dump_tracks:
+        if world > 1:   # one file per rank
+            args.dump_tracks = args.dump_tracks.replace(".npz", "_r%d.npz" % rank)
         np.savez(args.dump_tracks, frames=np.array(my_frames[:fps] if DIST else list(range(fps))),
                  **{"t%d" % i: rig.tracks(i, slot=0)[0] for i in range(fps)})
 

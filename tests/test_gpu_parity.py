@@ -613,3 +613,44 @@ def test_match_sets_device_resident_interframe_knn():
         prev = cur
     blk.close()
     rig.close()
+
+
+@pytest.mark.parametrize("C,F", [(2, 1), (4, 2), (4, 3), (4, 7), (4, 9)])
+def test_knn_chunk_lengths_by_pair_count(mc, C, F):
+    """k_knn2 walks the train set in chunks whose length depends on the pairs of the launch (knn_chunk_len: 256 up to 12 pairs,
+    512 up to 24, 1024 up to 48, else one chunk and the folded finalize): 1, 12, 18, 42 and 54 pairs here -- every branch, both
+    the partial-merging k_knn2_finalize and the in-kernel epilogue -- give the oracle's k-NN tables, accept lists and tracks."""
+    W, H, N = 640, 480, 700
+    rig = mc.Rig(C, W, H, F, 1, nfeatures=N)
+    rig.upload([mc.synth_rig_frame(10 + f, C, c, W, H) for f in range(F) for c in range(C)])
+    rig.process(F)
+    for f in range(F):
+        descs = [rig.features(f * C + c)[2] for c in range(C)]
+        assert min(len(d) for d in descs) > 300
+        otr, omg = O.intra_matches(descs)
+        tr, mg = rig.tracks(f)
+        assert np.array_equal(tr, otr) and mg == omg, "tracks, frame %d" % f
+        for i in range(C - 1):
+            for j in range(i + 1, C):
+                gi, gd = rig.pair_knn2(f, i, j)
+                oi, od = O.knn2(descs[i], descs[j])
+                assert np.array_equal(gi, oi) and np.array_equal(gd, od), "knn table frame %d pair (%d, %d)" % (f, i, j)
+                g1, g2 = rig.pair_matches(f, i, j)
+                o1, o2 = O.bruteforce_match(descs[i], descs[j])
+                assert np.array_equal(g1, o1) and np.array_equal(g2, o2)
+    rig.close()
+
+
+def test_n2_rehearsal_two_ranks_on_one_device():
+    """bench.py's N > 1 code paths with TWO ranks (two processes sharing device 0; the collectives over gloo on host tensors,
+    since RCCL refuses two ranks on one device): the all-to-all / frame partition and the all-gather / pair partition both end
+    with the tracks of the fused single-process path, frame by frame (scripts/rehearse_n2.sh)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    name = "n2_test_%d" % os.getpid()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run(["bash", os.path.join(root, "scripts", "rehearse_n2.sh"), name], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    shutil.rmtree(os.path.join(root, "gpurun_out", name), ignore_errors=True)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+    assert "all identical" in p.stdout and "20 frame track tables" in p.stdout, p.stdout[-1500:]
