@@ -704,6 +704,25 @@ int Rig::wait(int slot)
     return s.status;
 }
 
+// MCORB_LAT_PROF=1: where a synchronous PROCESS job spends its wall time (host clock), printed every 50 jobs
+namespace LatProf {
+static const bool on = getenv("MCORB_LAT_PROF") != nullptr;
+static thread_local double t[12];
+static thread_local double acc[12];
+static thread_local int n = 0;
+static inline void mark(int i) { if (on) t[i] = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static void flush()
+{
+    if (!on) return;
+    for (int i = 1; i < 9; i++) acc[i] += t[i] - t[i - 1];
+    if (++n % 50 == 0) {
+        fprintf(stderr, "[mcorb lat prof] per job: enqueue A %.0f us, wait tables %.0f, select %.0f, prepare+enqueue B %.0f, wait GPU %.0f, post %.0f, merge %.0f, total %.0f\n",
+                acc[1] / 50, acc[2] / 50, acc[3] / 50, acc[4] / 50, acc[5] / 50, acc[6] / 50, acc[7] / 50, (acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6] + acc[7]) / 50);
+        for (int i = 0; i < 12; i++) acc[i] = 0;
+    }
+}
+}  // namespace LatProf
+
 int Rig::execute(Slot &s, const Job &j)
 {
     int st = MCORB_OK;
@@ -713,9 +732,14 @@ int Rig::execute(Slot &s, const Job &j)
         if (st == MCORB_OK) st = run_select_and_describe(s, j, false);
         break;
     case Job::PROCESS:
+        LatProf::mark(0);
         st = run_extract_phaseA(s, j);
+        LatProf::mark(1);
         if (st == MCORB_OK) st = run_select_and_describe(s, j, true);
+        LatProf::mark(6);
         if (st == MCORB_OK) st = finish_match(s, j);
+        LatProf::mark(7);
+        LatProf::flush();
         break;
     case Job::MATCH:
         st = enqueue_match(s, j, false);
@@ -827,6 +851,7 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
 int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
 {
     HIPCHK(wait_event(s.ev[3]));
+    LatProf::mark(2);
     if (s.h_overflow[0]) {
         set_error("candidate list of a sparse level does not fit the host buffer (raise mcorb_params.cand_cap)");
         (void)hipStreamSynchronize(s.st);
@@ -835,8 +860,30 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     const auto t0 = std::chrono::steady_clock::now();
     const int L = geom.nlevels, nimg = j.nimg;
     std::atomic<int> bad{0};
-    // selection + assembly: one task per image.  (Splitting an image's levels over two tasks was measured slower for single
-    // rig frames -- the extra tasks only wait for sleeping workers to wake up -- and is gone.)
+    // selection of one level of one image (worker w's scratch)
+    auto select_level = [&](int m, int level, int w) {
+        const int *tb = s.tbl(m);
+        const int *lo = tb + kTblLvlOff, *shp = tb + kTblShipped;
+        const int *bst = tb + kTblHead;
+        const BucketWin *win = reinterpret_cast<const BucketWin *>(tb + tbl_win_off(geom.bucketTotal));
+        const int n = lo[level + 1] - lo[level];
+        std::vector<uint32_t> &out = s.sel_val[(size_t)m * L + level];
+        out.resize((size_t)tab.quota[level] + 64);
+        std::vector<int> &idx = scratch[w]->idx;
+        idx.resize(out.size());
+        int r = 0;
+        if (n > 0)
+            r = select_octree(shp[level] ? s.h_cand + (size_t)m * geom.hostCandCap + lo[level] : nullptr,
+                              bst + geom.lv[level].bucket0, win + geom.lv[level].bucket0, n, selp[level],
+                              idx.data(), out.data(), *scratch[w]);
+        if (r == -3) { bad.store(3); r = 0; }
+        if (r < 0) { bad.store(1); r = 0; }
+        out.resize(r);
+    };
+    // selection + assembly: one task per image.  (One task per (image, level) for single rig frames was measured slower twice:
+    // in round 2 the extra tasks waited for sleeping workers; in round 3, with the workers woken ahead of time and spinning, the
+    // selection still went from 83 to 106 us: the per-image task streams its tables into the cache once, 32 small tasks miss
+    // them one by one.  Waking the workers ahead of time by itself was worth 9 us of 92 for twelve spinning cores: not kept.)
     pool->parallel_for(nimg, [&](int m, int w) {
         HostProf::Scope prof_task(0);
         const int *tb = s.tbl(m);
@@ -860,23 +907,10 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
             }
             s.touch_sink[m & 15] = touch;   // keeps the loads alive
         }
-        HostProf::Scope *prof_sel = new (alloca(sizeof(HostProf::Scope))) HostProf::Scope(1);
-        for (int level = 0; level < L; level++) {
-            const int n = lo[level + 1] - lo[level];
-            std::vector<uint32_t> &out = s.sel_val[(size_t)m * L + level];
-            out.resize((size_t)tab.quota[level] + 64);
-            std::vector<int> &idx = scratch[w]->idx;
-            idx.resize(out.size());
-            int r = 0;
-            if (n > 0)
-                r = select_octree(shp[level] ? s.h_cand + (size_t)m * geom.hostCandCap + lo[level] : nullptr,
-                                  bst + geom.lv[level].bucket0, win + geom.lv[level].bucket0, n, selp[level],
-                                  idx.data(), out.data(), *scratch[w]);
-            if (r == -3) { bad.store(3); r = 0; }
-            if (r < 0) { bad.store(1); r = 0; }
-            out.resize(r);
+        {
+            HostProf::Scope prof_sel(1);
+            for (int level = 0; level < L; level++) select_level(m, level, w);
         }
-        prof_sel->~Scope();
         // assembly (ORBextractor.cpp:1103-1170): final order, lapping partition, coordinate scaling
         int total = 0;
         for (int l = 0; l < L; l++) total += (int)s.sel_val[(size_t)m * L + l].size();
@@ -914,6 +948,7 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     if (bad.load()) { set_error("keypoint capacity exceeded"); (void)hipStreamSynchronize(s.st); return MCORB_E_CAP; }
     const auto t1 = std::chrono::steady_clock::now();
     s.timing[1] = std::chrono::duration<float, std::micro>(t1 - t0).count();
+    LatProf::mark(3);
 
     s.nimg_done = nimg;
     if (then_match) TRY(prepare_match(s, j));
@@ -925,7 +960,9 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
         if (then_match) TRY(enqueue_match(s, j, true));
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(s.ev[10], s.st));
+        LatProf::mark(4);
         HIPCHK(wait_event(s.ev[10]));
+        LatProf::mark(5);
         s.nimg_done = nimg;
         float a = 0, c = 0, t = 0;
         (void)hipEventElapsedTime(&a, s.ev[0], s.ev[2]);
