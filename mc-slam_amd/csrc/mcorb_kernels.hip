@@ -1322,7 +1322,9 @@ __global__ __launch_bounds__(256) void k_describe_oriented(const uint8_t *__rest
     const float ang = fast_atan2_deg((float)m01, (float)m10);
     if (lane == 0) angles[(size_t)img * g.kcap + k] = ang;
     const float rad = __fmul_rn(ang, (float)(3.14159265358979323846 / 180.f));
-    const float ca = cosf(rad), sa = sinf(rad);
+    // the host libm's cosf / sinf are within 0.56 ulp, i.e. almost always the correctly rounded value: round the double
+    // result rather than use the device's 1-2 ulp float routines (a last-ulp difference can flip a rounded tap offset)
+    const float ca = (float)cos((double)rad), sa = (float)sin((double)rad);
 
     const uint8_t *cb = blur + (size_t)img * g.imgBytes + L.off;   // tiled 16 x 8 (mcorb_common.h)
     unsigned long long bits[4];
@@ -1883,7 +1885,8 @@ void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt
     static const int wg_env = getenv("MCORB_COMPACT_WG") ? atoi(getenv("MCORB_COMPACT_WG")) : 0;
     static const int cells_env = getenv("MCORB_COMPACT_CELLS") ? atoi(getenv("MCORB_COMPACT_CELLS")) : 0;
     // 512 threads per (level, image) workgroup is the optimum of a full batch (256: 136 us, 1024: 84-90 us, 512: 72 us per 128
-    // images); a small batch is the latency of its level-0 workgroup, and that one is shorter with 1024 (4 images: 39 vs 57 us)
+    // images); a small batch is the latency of its level-0 workgroup, and that one is shorter with 1024 (4 images: 39 vs 57 us).
+    // (Keeping the next group of cells' loads in flight while one group is processed changed nothing: 66.9 vs 68.5 us.)
     const int wg = wg_env == 1024 || wg_env == 256 || wg_env == 512 ? wg_env : (nimg <= 8 ? 1024 : 512), cellsInFlight = cells_env == 4 ? 4 : 8;
     const int cellsCap = (maxc + 8 + 7) & ~7;   // u16 entries, a multiple of 8
     const size_t lds = (size_t)(3 * bktCap) * sizeof(int) + (size_t)(cellsCap + maxwh + 8) * sizeof(uint16_t);

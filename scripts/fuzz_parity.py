@@ -92,6 +92,8 @@ def main():
         orient = int(os.environ.get("FUZZ_ORIENT", "0")) and int(rng.integers(0, 2))   # IC-angle mode (not the reference's default)
         img, kind = content(rng, W, H)
         tag = "case %d: %dx%d kind %d nf %d sf %.1f nl %d th %d/%d orient %d" % (case, W, H, kind, nf, sf, nl, ini, mn, orient)
+        if os.environ.get("FUZZ_ONLY") and case != int(os.environ["FUZZ_ONLY"]):   # same random stream, one case
+            continue
         try:
             ora = O.OracleExtractor(nf, sf, nl, ini, mn, orient)
             ref = ora(img, cap=nf + 64 * nl + 4096)
@@ -113,10 +115,25 @@ def main():
             print(tag, "oracle status", m1, "but GPU returned", m2)
             bad += m1 != m2
             continue
-        ok = m1 == m2 and len(k1) == len(k2) and all(np.array_equal(k1[f], k2[f]) for f in k1.dtype.names) and np.array_equal(d1, d2)
+        ok = m1 == m2 and len(k1) == len(k2) and all(np.array_equal(k1[f], k2[f]) for f in k1.dtype.names)
+        if ok and orient:   # rotated taps go through cos/sin of two different libms (tests/test_gpu_parity.py's orientation test)
+            same = np.all(d1 == d2, axis=1)
+            ok = len(same) == 0 or same.mean() >= 0.995
+            if ok and not same.all():
+                print(tag, "orientation mode: %d of %d descriptors differ (libm last-ulp)" % ((~same).sum(), len(same)))
+        elif ok:
+            ok = np.array_equal(d1, d2)
         if not ok:
             bad += 1
             print(tag, "MISMATCH", m1, m2, len(k1), len(k2))
+            if len(k1) == len(k2):
+                for f in k1.dtype.names:
+                    w = np.flatnonzero(k1[f] != k2[f])
+                    if len(w):
+                        print("   field %s: %d differ, first at %d: oracle %r gpu %r" % (f, len(w), w[0], k1[f][w[0]], k2[f][w[0]]))
+                w = np.flatnonzero((d1 != d2).any(1))
+                if len(w):
+                    print("   descriptors: %d rows differ, first at %d; keypoint there: oracle %r gpu %r" % (len(w), w[0], k1[w[0]], k2[w[0]]))
         elif case % 10 == 0:
             print(tag, "ok,", len(k1), "keypoints", flush=True)
     print("fuzz: %d cases, %d bad" % (ncases, bad))
