@@ -661,6 +661,10 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 // `depth` split iterations -- twice per candidate: 64 M vector instructions in 8192 long waves, 445 us per 128 images.
 // It was believed to be PCIe-bound; the same kernel writing to device memory took 408 us.)
 // ---------------------------------------------------------------------------
+// Private copies of every bucket's counter and winner key in LDS; lane & (copies - 1) picks one.  A cell's candidates fall into
+// one to four buckets, so most lanes of an LDS atomic hit the same address and are served one after the other: with four
+// copies a quarter as many (46 -> 39.6 us per 128 images; two: 40.3, eight: 39.3)
+constexpr int kCompactCopies = 4;
 template <int kCompactWaves>
 __device__ __forceinline__ int block_exclusive_scan(int v, int *wsum, int *total)   // 64 * kCompactWaves threads
 {
@@ -689,16 +693,16 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *wsum, int *total
 }
 
 template <int kCompactWG, int kCompactCells>
-__global__ __launch_bounds__(kCompactWG) void k_compact(const uint32_t *__restrict__ cell_kp, const int *__restrict__ cell_cnt,
+__global__ __launch_bounds__(kCompactWG, 8) void k_compact(const uint32_t *__restrict__ cell_kp, const int *__restrict__ cell_cnt,
                                                         Geom g, const uint16_t *__restrict__ lut, uint32_t *__restrict__ sorted_dev,
                                                         uint32_t *__restrict__ cand, int *__restrict__ tbl,
                                                         int *__restrict__ overflow, int bktCap, int cellsCap)
 {
-    extern __shared__ int sh[];     // hist[bktCap] | bkey[bktCap] | bval[bktCap] | cnts[cellsCap] (u16) | tx[W0], ty[H0] (u16)
+    extern __shared__ __attribute__((aligned(16))) int sh[];     // hist[bktCap] | bkey[bktCap] | cnts[cellsCap] (u16) | tx[W0], ty[H0] (u16)
     int *hist = sh;
-    uint32_t *bkey = reinterpret_cast<uint32_t *>(hist + bktCap);
-    uint32_t *bval = reinterpret_cast<uint32_t *>(hist + 2 * bktCap);   // the winner's packed candidate
-    uint16_t *cnts = reinterpret_cast<uint16_t *>(hist + 3 * bktCap);    // min(count, cellCap) of this level's cells
+    constexpr int NC = kCompactCopies;
+    uint32_t *bkey = reinterpret_cast<uint32_t *>(hist + NC * bktCap);
+    uint16_t *cnts = reinterpret_cast<uint16_t *>(hist + 2 * NC * bktCap);    // min(count, cellCap) of this level's cells
     constexpr int kCompactWaves = kCompactWG / 64;
     __shared__ int wsum[kCompactWaves];
     __shared__ int s_tot, s_base, s_nz;
@@ -721,12 +725,12 @@ __global__ __launch_bounds__(kCompactWG) void k_compact(const uint32_t *__restri
         cnts[c] = (uint16_t)v;
         t += v;
     }
-    for (int c = nc + tid; c < nc + kCompactCells; c += kCompactWG) cnts[c] = 0;   // the walk reads whole groups of cells
+    for (int c = nc + tid; c < min(nc + 2 * kCompactCells, cellsCap); c += kCompactWG) cnts[c] = 0;   // the walk reads whole groups of cells, one past the end too
     for (int i = tid; i < W0 + H0; i += kCompactWG) tx[i] = lut[L.lutx + i];        // (ty follows tx in both places)
     (void)block_exclusive_scan<kCompactWaves>(s, wsum, &s_base);
     (void)block_exclusive_scan<kCompactWaves>(t, wsum, &s_tot);
     const int base = s_base, T = s_tot;
-    for (int b = tid; b <= B; b += kCompactWG) { hist[b] = 0; bkey[b] = 0; bval[b] = 0; }
+    for (int b = tid; b < NC * (B + 1); b += kCompactWG) { hist[b] = 0; bkey[b] = 0; }
     int *tb = tbl + (size_t)img * tbl_ints(g.bucketTotal);   // this image's table block (device memory; DMA'd to the host afterwards)
     if (tid == 0) {
         s_nz = 0;
@@ -738,29 +742,72 @@ __global__ __launch_bounds__(kCompactWG) void k_compact(const uint32_t *__restri
     __syncthreads();
 
     const uint32_t *src = cell_kp + ((size_t)img * g.cells + L.cell0) * cap;
-    // visit every candidate of the level: wave = kCompactCells consecutive cells at a time, lane = index inside the cell;
-    // cells with more than 64 candidates take extra trips
-    auto for_each = [&](auto &&fn) {
-        for (int c0 = wave * kCompactCells; c0 < nc; c0 += kCompactWaves * kCompactCells) {
-            int n[kCompactCells];
-            uint32_t p[kCompactCells];
-#pragma unroll
-            for (int u = 0; u < kCompactCells; u++) {
-                n[u] = cnts[c0 + u];
-                p[u] = lane < n[u] ? src[(size_t)(c0 + u) * cap + lane] : 0u;
+    // Visit every candidate of the level: wave = kCompactCells consecutive cells at a time, lane = index inside the cell; cells
+    // with more than 64 candidates take extra trips afterwards (wave-uniform test).  Nothing stands in the way of the memory
+    // pipeline: the group's counts are ONE LDS read, the list loads are unconditional (lanes past a cell's count re-read its
+    // last entry: same cache line) and the next group's are in flight while this one is processed.  (As `lane < n ? load : 0`
+    // every load sat under its own branch behind its own LDS read of the count, and a wait that follows loads under branches
+    // is a wait for all of them; with eight cells per group the kernel also needed 83 registers, which halved the resident
+    // workgroups: levels 4 - 7 started when levels 0 - 3 were done.  67 -> 50 us per 128 images.)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto walk = [&](auto &&fn) {
+        static_assert(kCompactCells == 8 || kCompactCells == 4 || kCompactCells == 2, "the counts are read as one 4-, 8- or 16-byte word");
+        constexpr int step = kCompactWaves * kCompactCells;
+        const int ncUp = (nc + kCompactCells - 1) & ~(kCompactCells - 1);
+        auto load = [&](int c0, int *n, uint32_t *p) {
+            if constexpr (kCompactCells == 8) {
+                const uint4 q = *reinterpret_cast<const uint4 *>(cnts + c0);
+                n[0] = q.x & 0xffff; n[1] = q.x >> 16; n[2] = q.y & 0xffff; n[3] = q.y >> 16;
+                n[4] = q.z & 0xffff; n[5] = q.z >> 16; n[6] = q.w & 0xffff; n[7] = q.w >> 16;
+            } else if constexpr (kCompactCells == 4) {
+                const uint2 q = *reinterpret_cast<const uint2 *>(cnts + c0);
+                n[0] = q.x & 0xffff; n[1] = q.x >> 16; n[2] = q.y & 0xffff; n[3] = q.y >> 16;
+            } else {
+                const uint32_t q = *reinterpret_cast<const uint32_t *>(cnts + c0);
+                n[0] = q & 0xffff; n[1] = q >> 16;
             }
 #pragma unroll
             for (int u = 0; u < kCompactCells; u++) {
+                const uint32_t *cb = src + (size_t)min(c0 + u, nc - 1) * cap;   // wave-uniform (cells past the end have count 0)
+                p[u] = cb[min(lane, max(n[u], 1) - 1)];
+            }
+        };
+        auto run = [&](int c0, const int *n, const uint32_t *p) {
+            int big = 0;
+#pragma unroll
+            for (int u = 0; u < kCompactCells; u++) {
+                big |= n[u];
                 if (lane < n[u]) fn(p[u], (c0 + u) * cap + lane);
-                for (int k = lane + 64; k < n[u]; k += 64) fn(src[(size_t)(c0 + u) * cap + k], (c0 + u) * cap + k);
             }
+            if (big > 64) {
+#pragma unroll
+                for (int u = 0; u < kCompactCells; u++)
+                    for (int k = lane + 64; k < n[u]; k += 64) fn(src[(size_t)(c0 + u) * cap + k], (c0 + u) * cap + k);
+            }
+        };
+        int c0 = wave_u * kCompactCells;
+        if (c0 >= nc) return;
+        int nA[kCompactCells], nB[kCompactCells];
+        uint32_t pA[kCompactCells], pB[kCompactCells];
+        load(c0, nA, pA);
+        while (true) {
+            load(min(c0 + step, ncUp), nB, pB);   // cnts[nc ..] are zero: past the end nothing new is loaded
+            run(c0, nA, pA);
+            c0 += step;
+            if (c0 >= nc) break;
+            load(min(c0 + step, ncUp), nA, pA);
+            run(c0, nB, pB);
+            c0 += step;
+            if (c0 >= nc) break;
         }
     };
     // pass 1: histogram of path codes + per-bucket winner key
-    for_each([&](uint32_t p, int order) {
+    walk([&](uint32_t p, int order) {
         const uint32_t code = (uint32_t)tx[cand_x(p)] | (uint32_t)ty[cand_y(p)];
-        atomicAdd(&hist[code], 1);
-        atomicMax(&bkey[code], ((uint32_t)cand_resp(p) << 23) | (uint32_t)(kPickOrderMask - order));
+        const uint32_t key = ((uint32_t)cand_resp(p) << 23) | (uint32_t)(kPickOrderMask - order);
+        const int slot = (int)code * NC + (lane & (NC - 1));
+        atomicAdd(&hist[slot], 1);
+        atomicMax(&bkey[slot], key);
     });
     __syncthreads();
     // bucket starts: exclusive scan of the histogram (each thread owns a contiguous run of buckets)
@@ -768,30 +815,45 @@ __global__ __launch_bounds__(kCompactWG) void k_compact(const uint32_t *__restri
         const int bper = (B + kCompactWG - 1) / kCompactWG;
         const int b0 = tid * bper;
         int bs = 0, nzl = 0;
-        for (int k = 0; k < bper; k++) if (b0 + k < B) { bs += hist[b0 + k]; nzl += hist[b0 + k] > 0; }
+        for (int k = 0; k < bper; k++)
+            if (b0 + k < B) {
+                int v = 0;
+#pragma unroll
+                for (int c = 0; c < NC; c++) v += hist[(b0 + k) * NC + c];
+                bs += v;
+                nzl += v > 0;
+            }
         if (nzl) atomicAdd(&s_nz, nzl);
         int brun = block_exclusive_scan<kCompactWaves>(bs, wsum, &s_tot);
         for (int k = 0; k < bper; k++) {
-            if (b0 + k < B) { const int v = hist[b0 + k]; hist[b0 + k] = brun; brun += v; }
+            if (b0 + k < B) {
+#pragma unroll
+                for (int c = 0; c < NC; c++) { const int v = hist[(b0 + k) * NC + c]; hist[(b0 + k) * NC + c] = brun; brun += v; }
+            }
         }
-        if (tid == 0) hist[B] = T;
+        if (tid == 0) hist[B * NC] = T;
     }
     __syncthreads();
     int *bs_out = tb + kTblHead + L.bucket0;
-    for (int b = tid; b <= B; b += kCompactWG) bs_out[b] = hist[b];
+    for (int b = tid; b <= B; b += kCompactWG) bs_out[b] = hist[b * NC];
     __syncthreads();
     // pass 2: scatter into bucket order (device memory), hist[] now counts up from each bucket's start
     uint32_t *sd = sorted_dev + (size_t)img * g.candCap + base;
     const int room = g.candCap - base;   // (the device list is sized for the worst case; stay in bounds regardless)
-    for_each([&](uint32_t p, int order) {
+    walk([&](uint32_t p, int) {
         const uint32_t code = (uint32_t)tx[cand_x(p)] | (uint32_t)ty[cand_y(p)];
-        const int slot = atomicAdd(&hist[code], 1);
+        const int slot = atomicAdd(&hist[(int)code * NC + (lane & (NC - 1))], 1);
         if (slot < room) sd[slot] = p;
-        if (bkey[code] == (((uint32_t)cand_resp(p) << 23) | (uint32_t)(kPickOrderMask - order))) bval[code] = p;   // keys are unique
     });
     __syncthreads();   // the workgroup's own global stores are visible to it after the barrier
     uint2 *bb_out = reinterpret_cast<uint2 *>(tb + tbl_win_off(g.bucketTotal)) + L.bucket0;   // BucketWin {key, val}
-    for (int b = tid; b < B; b += kCompactWG) bb_out[b] = uint2{bkey[b], bval[b]};
+    // the winner itself: its key holds its position in the cell lists (order = cell * cap + index)
+    for (int b = tid; b < B; b += kCompactWG) {
+        uint32_t k = 0;
+#pragma unroll
+        for (int c = 0; c < NC; c++) k = max(k, bkey[b * NC + c]);
+        bb_out[b] = uint2{k, k ? src[kPickOrderMask - (k & (uint32_t)kPickOrderMask)] : 0u};
+    }
     // The list itself goes over PCIe only when the host can need it: DistributeOctTree divides a depth-D node (one
     // bucket) only after every node reached depth D with fewer than N nodes in total, and at that point the node count
     // equals the number of non-empty buckets.  With nz >= N the host works from the bucket tables alone.
@@ -1884,18 +1946,17 @@ void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt
     const int bktCap = (maxb + 1 + 3) & ~3;
     static const int wg_env = getenv("MCORB_COMPACT_WG") ? atoi(getenv("MCORB_COMPACT_WG")) : 0;
     static const int cells_env = getenv("MCORB_COMPACT_CELLS") ? atoi(getenv("MCORB_COMPACT_CELLS")) : 0;
-    // 512 threads per (level, image) workgroup is the optimum of a full batch (256: 136 us, 1024: 84-90 us, 512: 72 us per 128
-    // images); a small batch is the latency of its level-0 workgroup, and that one is shorter with 1024 (4 images: 39 vs 57 us).
-    // (Keeping the next group of cells' loads in flight while one group is processed changed nothing: 66.9 vs 68.5 us.)
-    const int wg = wg_env == 1024 || wg_env == 256 || wg_env == 512 ? wg_env : (nimg <= 8 ? 1024 : 512), cellsInFlight = cells_env == 4 ? 4 : 8;
+    // 512 threads per (level, image) workgroup and four cells per group for a full batch (1024 threads: 42 against 39.5 us per
+    // 128 images; two cells: 45.6; eight cells need more than 64 registers, which halves the resident workgroups); a small
+    // batch is the latency of its level-0 workgroup, shorter with 1024 threads
+    const int wg = wg_env == 1024 || wg_env == 512 ? wg_env : (nimg <= 8 ? 1024 : 512), cellsInFlight = cells_env == 2 ? 2 : 4;
     const int cellsCap = (maxc + 8 + 7) & ~7;   // u16 entries, a multiple of 8
-    const size_t lds = (size_t)(3 * bktCap) * sizeof(int) + (size_t)(cellsCap + maxwh + 8) * sizeof(uint16_t);
+    const size_t lds = (size_t)(2 * kCompactCopies * bktCap) * sizeof(int) + (size_t)(cellsCap + maxwh + 8) * sizeof(uint16_t);
     const dim3 grid(nimg, g.nlevels);
 #define MCORB_COMPACT_LAUNCH(WG_, C_) \
     hipLaunchKernelGGL((k_compact<WG_, C_>), grid, dim3(WG_), lds, st, cell_kp, cell_cnt, g, lut, sorted_dev, cand, tbl, overflow, bktCap, cellsCap)
-    if (wg == 1024) { if (cellsInFlight == 4) MCORB_COMPACT_LAUNCH(1024, 4); else MCORB_COMPACT_LAUNCH(1024, 8); }
-    else if (wg == 256) { if (cellsInFlight == 4) MCORB_COMPACT_LAUNCH(256, 4); else MCORB_COMPACT_LAUNCH(256, 8); }
-    else { if (cellsInFlight == 4) MCORB_COMPACT_LAUNCH(512, 4); else MCORB_COMPACT_LAUNCH(512, 8); }
+    if (wg == 1024) { if (cellsInFlight == 2) MCORB_COMPACT_LAUNCH(1024, 2); else MCORB_COMPACT_LAUNCH(1024, 4); }
+    else { if (cellsInFlight == 2) MCORB_COMPACT_LAUNCH(512, 2); else MCORB_COMPACT_LAUNCH(512, 4); }
 #undef MCORB_COMPACT_LAUNCH
 }
 
