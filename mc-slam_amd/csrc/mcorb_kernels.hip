@@ -1222,6 +1222,8 @@ __device__ __forceinline__ void fd_wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   // a wave only ever reads what it wrote itself
 }
 
+// (65 registers: seven waves per SIMD where the LDS would allow eight; capped at 64 the compiler spills three and the kernel
+// takes 131 instead of 110 us)
 __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restrict__ pyr, Geom g,
                                                         const uint32_t *__restrict__ sel, const int *__restrict__ nsel,
                                                         uint8_t *__restrict__ desc, int groups, uint8_t *__restrict__ desc_host)
