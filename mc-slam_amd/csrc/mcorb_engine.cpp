@@ -883,7 +883,9 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     // selection + assembly: one task per image.  (One task per (image, level) for single rig frames was measured slower twice:
     // in round 2 the extra tasks waited for sleeping workers; in round 3, with the workers woken ahead of time and spinning, the
     // selection still went from 83 to 106 us: the per-image task streams its tables into the cache once, 32 small tasks miss
-    // them one by one.  Waking the workers ahead of time by itself was worth 9 us of 92 for twelve spinning cores: not kept.)
+    // them one by one.  Waking the workers ahead of time by itself was worth 9 us of 92 for twelve spinning cores: not kept.
+    // Two tasks per image (levels {0, 3, 4, 7} and {1, 2, 5, 6}; the one that finishes second assembles) with workers that
+    // spin for 1 ms between jobs: 88 - 92 against 76 - 87 us: not kept either.)
     pool->parallel_for(nimg, [&](int m, int w) {
         HostProf::Scope prof_task(0);
         const int *tb = s.tbl(m);
