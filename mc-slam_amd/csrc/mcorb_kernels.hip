@@ -521,7 +521,8 @@ __device__ __forceinline__ int fast_arc_score(const uint8_t *tile, int pos)   //
 // compile-time constant so that the ring / neighbour offsets fold into the ds_read offset fields.
 // One wave per cell.  (Several cells per wave, one after the other with the next ROI prefetched into registers, or two
 // cells with pooled survivor lists, were measured slower: the extra LDS / SGPRs cost more occupancy than they save --
-// 443-456 us and 787 us against 431 us per 128 images.)
+// 443-456 us and 787 us against 431 us per 128 images.  Round 3, a plain loop over 2 / 3 / 4 / 8 consecutive cells in the same
+// wave, nothing prefetched, no extra registers: 394 / 367 / 373 / 419 against 348 us.)
 // LDS of the wave: [16 B][tile, tileB][16 B][score map of ROI rows 2 .. rows-3, scB][16 B][work list, cap x 2 B; its second
 // half doubles as the group list of pass 1] = 5.4 KiB at TP = 48; <= 80 SGPRs and <= 64 VGPRs leave 8 waves per SIMD.
 template <int TP>
