@@ -1224,7 +1224,8 @@ __device__ __forceinline__ void fd_wave_sync()
 }
 
 // (65 registers: seven waves per SIMD where the LDS would allow eight; capped at 64 the compiler spills three and the kernel
-// takes 131 instead of 110 us)
+// takes 131 instead of 110 us; with the tap offsets packed two to a register it needs 61 and runs eight waves: 109 us, no
+// gain -- the kernel is held by vector issue and the LDS pipe together, not by waves to switch to)
 __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restrict__ pyr, Geom g,
                                                         const uint32_t *__restrict__ sel, const int *__restrict__ nsel,
                                                         uint8_t *__restrict__ desc, int groups, uint8_t *__restrict__ desc_host)
