@@ -1527,7 +1527,8 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
             for (int s = 0; s < 8; s++) Bf[u][s] = __builtin_bit_cast(v4i, src[s * 64]);
         }
         // ninth K-step, query side: multipliers (1, 64) on k = 0, 1 (lane half 0, bytes 0, 1)
-        const v4i B9 = {half == 0 ? 0x4001 : 0, 0, 0, 0};
+        // (two k of the step are used: the 16-deep multiply does it in half the matrix-pipe time of a 32-deep one)
+        const long B9 = half == 0 ? 0x4001L : 0L;
         const uint4 *Et = E + ((size_t)qt.y * tilesPerSet + (t0 >> 5)) * kTileU4;
         const int nstage = (tn + 32 * kKnnStageTiles - 1) / (32 * kKnnStageTiles);
         constexpr int kPer = kKnnStageTiles * kTileU4 / (64 * kKnnWaves);   // 1-KiB wave transfers per wave per stage (4)
@@ -1583,9 +1584,9 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
             }
             {   // ninth K-step, train side: 8191 - (index inside the chunk) as two digits of base 64
                 const int iv = 8191 - (tb + (lane & 31));
-                const v4i A9 = {half == 0 ? ((iv & 63) | ((iv >> 6) << 8)) : 0, 0, 0, 0};
+                const long A9 = half == 0 ? (long)((iv & 63) | ((iv >> 6) << 8)) : 0L;
 #pragma unroll
-                for (int u = 0; u < kKnnQT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(A9, B9, acc[u], 0, 0, 0);
+                for (int u = 0; u < kKnnQT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x16_i8(A9, B9, acc[u], 0, 0, 0);
             }
             if (tb + 32 > tn) {   // last tile of the set: rows past the end hold stale bytes
 #pragma unroll
@@ -1601,6 +1602,10 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
         const v16i allMin = {kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin};
 #pragma unroll
         for (int u = 0; u < kKnnQT; u++) accA[u] = allMin;   // "nothing pending": folding it changes nothing
+        // (An odd tile count ends in the else branch below, on the last stage.  It used to leave "nothing pending" in accA for
+        // the fold behind the loop: the compiler set those 32 registers in EVERY stage, ahead of the branch -- 18 % of the
+        // loop's vector instructions, in a kernel whose vector issue port is as full as its matrix pipe.  A flag instead.)
+        bool pendingA = true;
         for (int st = 0; st < nstage; st++) {
             if (st + 1 < nstage) fill(st + 1, (st + 1) & 1);   // travels while this stage is multiplied (that buffer was last read a barrier ago)
             const uint4 *S = stage[st & 1];
@@ -1610,13 +1615,12 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
                 mm_fold(S, 1, tb1, accA, accB);
             } else {
                 top2(accB);
-#pragma unroll
-                for (int u = 0; u < kKnnQT; u++) accA[u] = allMin;
+                pendingA = false;   // (st is the last stage: tb1 >= tn)
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next stage has landed
             __syncthreads();
         }
-        top2(accA);
+        if (pendingA) top2(accA);
     }
     // the two lane halves hold different train rows of the same query columns: merge, convert, store
     auto conv = [&](int key) -> uint32_t {
