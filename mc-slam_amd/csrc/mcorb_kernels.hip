@@ -664,7 +664,8 @@ __global__ __launch_bounds__(64) void k_fast_cells(const uint8_t *__restrict__ p
 // ---------------------------------------------------------------------------
 // Private copies of every bucket's counter and winner key in LDS; lane & (copies - 1) picks one.  A cell's candidates fall into
 // one to four buckets, so most lanes of an LDS atomic hit the same address and are served one after the other: with four
-// copies a quarter as many (46 -> 39.6 us per 128 images; two: 40.3, eight: 39.3)
+// copies a quarter as many (46 -> 39.6 us per 128 images; two: 40.3, eight: 39.3).  One copy when four would not fit 64 KiB
+// of LDS (levels with thousands of buckets: very large feature budgets on wide images).
 constexpr int kCompactCopies = 4;
 template <int kCompactWaves>
 __device__ __forceinline__ int block_exclusive_scan(int v, int *wsum, int *total)   // 64 * kCompactWaves threads
@@ -693,7 +694,7 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *wsum, int *total
     return wsum[wave] + s - v;
 }
 
-template <int kCompactWG, int kCompactCells>
+template <int kCompactWG, int kCompactCells, int NC>
 __global__ __launch_bounds__(kCompactWG, 8) void k_compact(const uint32_t *__restrict__ cell_kp, const int *__restrict__ cell_cnt,
                                                         Geom g, const uint16_t *__restrict__ lut, uint32_t *__restrict__ sorted_dev,
                                                         uint32_t *__restrict__ cand, int *__restrict__ tbl,
@@ -701,7 +702,6 @@ __global__ __launch_bounds__(kCompactWG, 8) void k_compact(const uint32_t *__res
 {
     extern __shared__ __attribute__((aligned(16))) int sh[];     // hist[bktCap] | bkey[bktCap] | cnts[cellsCap] (u16) | tx[W0], ty[H0] (u16)
     int *hist = sh;
-    constexpr int NC = kCompactCopies;
     uint32_t *bkey = reinterpret_cast<uint32_t *>(hist + NC * bktCap);
     uint16_t *cnts = reinterpret_cast<uint16_t *>(hist + 2 * NC * bktCap);    // min(count, cellCap) of this level's cells
     constexpr int kCompactWaves = kCompactWG / 64;
@@ -1959,10 +1959,15 @@ void launch_compact(hipStream_t st, const uint32_t *cell_kp, const int *cell_cnt
     // batch is the latency of its level-0 workgroup, shorter with 1024 threads
     const int wg = wg_env == 1024 || wg_env == 512 ? wg_env : (nimg <= 8 ? 1024 : 512), cellsInFlight = cells_env == 2 ? 2 : 4;
     const int cellsCap = (maxc + 8 + 7) & ~7;   // u16 entries, a multiple of 8
-    const size_t lds = (size_t)(2 * kCompactCopies * bktCap) * sizeof(int) + (size_t)(cellsCap + maxwh + 8) * sizeof(uint16_t);
+    const size_t ldsTail = (size_t)(cellsCap + maxwh + 8) * sizeof(uint16_t);
+    const bool fits = (size_t)(2 * kCompactCopies * bktCap) * sizeof(int) + ldsTail <= 64 * 1024;
+    static const bool one_env = getenv("MCORB_COMPACT_ONE_COPY") != nullptr;   // (test / comparison knob)
+    const int copies = fits && !one_env ? kCompactCopies : 1;
+    const size_t lds = (size_t)(2 * copies * bktCap) * sizeof(int) + ldsTail;
     const dim3 grid(nimg, g.nlevels);
 #define MCORB_COMPACT_LAUNCH(WG_, C_) \
-    hipLaunchKernelGGL((k_compact<WG_, C_>), grid, dim3(WG_), lds, st, cell_kp, cell_cnt, g, lut, sorted_dev, cand, tbl, overflow, bktCap, cellsCap)
+    do { if (copies == 1) hipLaunchKernelGGL((k_compact<WG_, C_, 1>), grid, dim3(WG_), lds, st, cell_kp, cell_cnt, g, lut, sorted_dev, cand, tbl, overflow, bktCap, cellsCap); \
+         else hipLaunchKernelGGL((k_compact<WG_, C_, kCompactCopies>), grid, dim3(WG_), lds, st, cell_kp, cell_cnt, g, lut, sorted_dev, cand, tbl, overflow, bktCap, cellsCap); } while (0)
     if (wg == 1024) { if (cellsInFlight == 2) MCORB_COMPACT_LAUNCH(1024, 2); else MCORB_COMPACT_LAUNCH(1024, 4); }
     else { if (cellsInFlight == 2) MCORB_COMPACT_LAUNCH(512, 2); else MCORB_COMPACT_LAUNCH(512, 4); }
 #undef MCORB_COMPACT_LAUNCH

@@ -63,6 +63,19 @@ def _content(kind, W=800, H=600):
     return np.clip(base, 0, 255).astype(np.uint8)
 
 
+@pytest.mark.parametrize("W,H,nfeat", [(1800, 600, 7000), (1280, 720, 6000)])
+def test_large_feature_budget_on_a_wide_image(mc, W, H, nfeat):
+    """Level 0 gets > 1 300 features: the quad-tree bucketing goes to depth 5 (3 x 1024 / 2 x 1024 buckets), where k_compact's four
+    private counter copies no longer fit 64 KiB of LDS and it runs with one; noise content so that the budget is really used."""
+    rng = np.random.default_rng(W + nfeat)
+    img = np.clip(mc.synth_rig_frame(3, 1, 0, W, H).astype(np.int32) + rng.integers(-60, 61, (H, W)), 0, 255).astype(np.uint8)
+    ora = O.OracleExtractor(nfeat)
+    ext = mc.ORBextractor(nfeat, 1.2, 8, 20, 7)
+    ref = ora(img, cap=nfeat + 4096)
+    same(ref, ext(img), "%dx%d nfeatures %d" % (W, H, nfeat))
+    assert len(ref[1]) > 0.8 * nfeat
+
+
 @pytest.mark.parametrize("kind", ["low_contrast", "noise", "saturated", "gradient", "clustered"])
 def test_image_content(mc, kind):
     img = _content(kind)
