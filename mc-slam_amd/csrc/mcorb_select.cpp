@@ -35,7 +35,10 @@ struct SelectScratch::Impl {
     std::vector<Node> nodes;
     std::vector<int> arena;
     std::vector<uint8_t> quad;
-    std::vector<std::pair<int, int>> expand, prevExpand;
+    // nodes that can still be divided: (key count << 12 | UL.x) in the upper half, the node's index in the lower -- compareNodes
+    // (:537-552) looks at exactly those two fields, so the sort compares upper halves and never touches the node array
+    std::vector<uint64_t> expand, prevExpand;
+    static uint64_t expand_entry(int cnt, int x0, int id) { return ((uint64_t)(((uint32_t)cnt << 12) | (uint32_t)x0) << 32) | (uint32_t)id; }
     int head = -1, tail = -1, count = 0;
 
     int new_node() { nodes.emplace_back(); return (int)nodes.size() - 1; }
@@ -76,13 +79,12 @@ static bool divide(SelectScratch::Impl &S, const uint32_t *cand, const int *bsta
     int cnt[4], beg[4];
     bool in_arena = false;
     if (P.d < D) {
-        // children are bucket ranges of the GPU-sorted array
+        // children are bucket ranges of the GPU-sorted array: five consecutive boundaries
         const int shift = 2 * (D - P.d - 1);
-        for (int q = 0; q < 4; q++) {
-            const uint32_t c = (P.code << 2) | (uint32_t)q;
-            beg[q] = bstart[c << shift];
-            cnt[q] = bstart[(c + 1) << shift] - beg[q];
-        }
+        const int *b = bstart + ((size_t)(P.code << 2) << shift);
+        const int e0 = b[0], e1 = b[(size_t)1 << shift], e2 = b[(size_t)2 << shift], e3 = b[(size_t)3 << shift], e4 = b[(size_t)4 << shift];
+        beg[0] = e0; beg[1] = e1; beg[2] = e2; beg[3] = e3;
+        cnt[0] = e1 - e0; cnt[1] = e2 - e1; cnt[2] = e3 - e2; cnt[3] = e4 - e3;
     } else {
         if (!cand) return false;   // the candidate list was not shipped: cannot happen when nz >= N (see k_compact)
         in_arena = true;
@@ -106,15 +108,16 @@ static bool divide(SelectScratch::Impl &S, const uint32_t *cand, const int *bsta
     for (int q = 0; q < 4; q++) {
         child[q] = -1;
         if (cnt[q] == 0) continue;
-        const int c = S.new_node();
-        Node &n = S.nodes[c];
+        Node n;
         n.x0 = bx0[q]; n.x1 = bx1[q]; n.y0 = by0[q]; n.y1 = by1[q];
         n.d = P.d + 1;
         n.code = (P.code << 2) | (uint32_t)q;
         n.beg = beg[q]; n.cnt = cnt[q];
         n.arena = in_arena;
+        n.prev = n.next = -1;
         n.noMore = (cnt[q] == 1);
-        child[q] = c;
+        child[q] = (int)S.nodes.size();
+        S.nodes.push_back(n);
     }
     return true;
 }
@@ -172,7 +175,7 @@ int select_octree(const uint32_t *cand, const int *bstart, const BB *bbest, int 
                 S.push_front(ch[q]);
                 if (S.nodes[ch[q]].cnt > 1) {
                     nToExpand++;
-                    S.expand.emplace_back(S.nodes[ch[q]].cnt, ch[q]);
+                    S.expand.push_back(SelectScratch::Impl::expand_entry(S.nodes[ch[q]].cnt, S.nodes[ch[q]].x0, ch[q]));
                 }
             }
             it = S.erase(it);
@@ -184,22 +187,17 @@ int select_octree(const uint32_t *cand, const int *bstart, const BB *bbest, int 
                 prevSize = S.count;
                 S.prevExpand = S.expand;
                 S.expand.clear();
-                const std::vector<Node> &nodes = S.nodes;
-                // compareNodes (:537-552); equivalent entries land where std::sort puts them
-                std::sort(S.prevExpand.begin(), S.prevExpand.end(),
-                          [&nodes](const std::pair<int, int> &e1, const std::pair<int, int> &e2) {
-                              if (e1.first < e2.first) return true;
-                              else if (e1.first > e2.first) return false;
-                              else return nodes[e1.second].x0 < nodes[e2.second].x0;
-                          });
+                // compareNodes (:537-552): (count, UL.x) ascending; equivalent entries land where std::sort puts them -- the
+                // same algorithm on the same sequence with a predicate that answers the same for every pair
+                std::sort(S.prevExpand.begin(), S.prevExpand.end(), [](uint64_t e1, uint64_t e2) { return (e1 >> 32) < (e2 >> 32); });
                 for (int j = (int)S.prevExpand.size() - 1; j >= 0; j--) {
-                    const int id = S.prevExpand[j].second;
+                    const int id = (int)(uint32_t)S.prevExpand[j];
                     int ch[4];
                     if (!divide(S, cand, bstart, D, id, ch)) return -3;
                     for (int q = 0; q < 4; q++) {
                         if (ch[q] < 0) continue;
                         S.push_front(ch[q]);
-                        if (S.nodes[ch[q]].cnt > 1) S.expand.emplace_back(S.nodes[ch[q]].cnt, ch[q]);
+                        if (S.nodes[ch[q]].cnt > 1) S.expand.push_back(SelectScratch::Impl::expand_entry(S.nodes[ch[q]].cnt, S.nodes[ch[q]].x0, ch[q]));
                     }
                     S.erase(id);
                     if (S.count >= N) break;
