@@ -1147,8 +1147,18 @@ void merge_pair_lists(int C, const int *counts, const uint32_t *const *idx1, con
 {
     tr.clear();
     int ntr = 0, mergeable = 0;
-    std::vector<std::vector<int>> inv(C);
-    for (int c = 0; c < C; c++) inv[c].assign(std::max(counts[c], 0), -1);
+    // keypoint -> track, one flat table for all cameras (per thread: this runs once per rig frame, on pool threads)
+    static thread_local std::vector<int> inv_flat;
+    int *inv[MCORB_MAX_CAMS];
+    {
+        size_t total = 0, worst = 0;
+        for (int c = 0; c < C; c++) total += (size_t)std::max(counts[c], 0);
+        inv_flat.assign(total, -1);
+        size_t o = 0;
+        for (int c = 0; c < C; c++) { inv[c] = inv_flat.data() + o; o += (size_t)std::max(counts[c], 0); }
+        for (int p = 0; p < C * (C - 1) / 2; p++) worst += (size_t)std::max(np[p], 0);
+        tr.reserve(worst * C);   // a track per accepted match at most
+    }
     int pl = 0;
     for (int a = 0; a < C - 1; a++) {
         for (int b = a + 1; b < C; b++, pl++) {
