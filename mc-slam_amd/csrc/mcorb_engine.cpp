@@ -1228,7 +1228,7 @@ int Rig::finish_match(Slot &s, const Job &j)
         i1.resize(n); i2.resize(n);
         int k = 0;
         for (int b = 0; b < nqb; b++)
-            for (int e = 0; e < cnt[b]; e++, k++) { i1[k] = ml[b * 256 + e] >> 16; i2[k] = ml[b * 256 + e] & 0xffffu; }
+            for (int e = 0; e < cnt[b]; e++, k++) { i1[k] = ml[b * kKnnQueriesPerBlock + e] >> 16; i2[k] = ml[b * kKnnQueriesPerBlock + e] & 0xffffu; }
     };
     auto one_frame = [&](int f, int w) {
         for (int pi = f * npp; pi < (f + 1) * npp; pi++) filter_pair(pi, w);

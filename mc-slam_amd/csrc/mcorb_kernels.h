@@ -14,8 +14,9 @@ constexpr int kKnnChunk = 4096;  // train descriptors per k-NN partial (one work
 __host__ __device__ inline int knn_chunk_len(int npairs) { return npairs <= 12 ? 256 : npairs <= 24 ? 512 : npairs <= 48 ? 1024 : kKnnChunk; }
 // The accepted (query << 16 | train) pairs of a camera pair come back in blocks of 256 queries: mlist[pair][block * 256 + k],
 // k < mcount[pair * knn_qblocks(kcap) + block]; blocks are in query order (concatenate them).
-inline int knn_qblocks(int kcap) { return (kcap + 255) / 256; }
-inline size_t knn_mlist_stride(int kcap) { return (size_t)knn_qblocks(kcap) * 256; }
+constexpr int kKnnQueriesPerBlock = 256;   // = the k-NN workgroup's queries (64 per wave x 4 waves; static_assert in mcorb_kernels.hip)
+inline int knn_qblocks(int kcap) { return (kcap + kKnnQueriesPerBlock - 1) / kKnnQueriesPerBlock; }
+inline size_t knn_mlist_stride(int kcap) { return (size_t)knn_qblocks(kcap) * kKnnQueriesPerBlock; }
 // partials (uint2) a slot needs for jobs of up to max_pairs pairs at capacity kcap
 inline size_t knn_part_entries(int max_pairs, int kcap)
 {
@@ -27,7 +28,7 @@ inline size_t knn_part_entries(int max_pairs, int kcap)
     }
     return need;
 }
-constexpr int kKnnExpandBytes = 256;   // bytes of one descriptor expanded to +-64 int8 (k_expand)
+constexpr int kKnnExpandBytes = 128;   // bytes of one descriptor expanded to 256 e2m1 nibbles of +-1 (k_expand)
 
 // one row of the knnMatch(k=2) table, 8 bytes so the PCIe write-back stays small:
 // idx = trainIdx0 | trainIdx1 << 16 (0xffff = absent), d = dist0 | dist1 << 9 | accept << 18

@@ -1434,34 +1434,45 @@ __global__ __launch_bounds__(256) void k_describe_oriented(const uint8_t *__rest
 }
 
 // ---------------------------------------------------------------------------
-// All-pairs Hamming k-NN, k = 2 (BFMatcher knnMatch, MultiCameraFrame.cpp:1053-1055) on the matrix cores.
+// All-pairs Hamming k-NN, k = 2 (BFMatcher knnMatch, MultiCameraFrame.cpp:1053-1055) on the matrix cores, FP4 form.
 //
-// Hamming(a, b) over 256 bits is a dense contraction: with every bit expanded to an int8 of +-64,
-//   dot(Ea, Eb) = 4096 * (256 - 2 * hamming)            (exact in the i32 accumulator, |dot| <= 2^20)
-// so one v_mfma_i32_32x32x32_i8 tile (32 trains x 32 queries, 8 K-steps of 32 bits) yields 1024 distances in 256
-// cycles, against 78 cycles per 64 distances for the xor + v_bcnt formulation (19.5 vector instructions each,
-// which ran at 90 % of ITS ceiling in round 1).  A ninth K-step adds 8191 - trainIndex (as 1 * (i & 63) +
-// 64 * (i >> 6)), smaller than one distance step of 8192, so the accumulator IS the sort key:
-//   key = 8192 * (128 - hamming) + (8191 - trainIndex)   larger key <=> smaller (distance, index),
-// i.e. knnMatch's order including its lowest-index tie-break, with no per-element index arithmetic.  Every lane owns
-// one query column (16 train rows of it per tile): the running two largest keys cost v_max + v_med3 per element.
-// Results are converted back to the (distance << 16 | trainIndex) partials k_knn2_finalize merges.
+// Hamming(a, b) over 256 bits is a dense contraction: with every bit expanded to +-1,
+//   dot(Ea, Eb) = 256 - 2 * hamming.
+// +-1 is exact in e2m1 (nibbles 0x2 / 0xA), gfx950's block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 multiplies 64 of them
+// per row and step in the time v_mfma_i32_32x32x32_i8 takes for 32 bytes (32.6 cycles either way, tools/fp4_probe.hip), and
+// its f32 accumulator holds every value that occurs here exactly (integers below 2^21; the probe checks all 1024 elements
+// of random, near-duplicate and extreme tiles against the CPU): 4 K-steps per 32 x 32 tile instead of round 3's 8 + 1, and
+// 128 expanded bytes per descriptor instead of 256.  Both block scales are 2^6, so a product is +-4096 and
+//   acc = 4096 * (256 - 2 * hamming) + C.
+// The tie-break rides in C, the accumulator input of a tile's first step: C = 31 - (train row inside the tile), a
+// per-lane constant (16 registers), so a tile's accumulator is its sort key RELATIVE to the tile,
+//   key' = 8192 * (128 - hamming) + (31 - row),      global key = key' + 8160 - 32 * tile  (= ... + 8191 - trainIndex),
+// and instead of adding the tile term to 16 elements the two running maxima are raised by 32 per tile (they are kept
+// relative to the tile being folded).  Larger key <=> smaller (distance, index) = knnMatch's order with its lowest-index
+// tie-break.  Every lane owns one query column (16 train rows of it per tile); the running top-2 of two new keys x, y is
+//   k1 = max(k1, med3(k0, x, y)), k0 = max3(k0, x, y)
+// (the second largest of {k0, k1, x, y} when k1 <= k0), which the compiler pairs up further: 5 vector instructions per 4
+// keys (v_med3 x2, v_max3 x3) where the integer form needed 8.  Results are converted back to the
+// (distance << 16 | trainIndex) partials k_knn2_finalize merges.
 //
-// k_expand writes the +-64 bytes in MFMA FRAGMENT ORDER, [tile of 32 descriptors][K-step][lane = half * 32 + row][16 B],
-// so that a wave's A or B operand of one K-step is 1 KiB of consecutive memory: query fragments are loaded straight
-// into registers (coalesced), train tiles are copied linearly into LDS and read back conflict-free with ds_read_b128.
-// The lane -> k mapping inside a fragment is the same for A and B, whatever the hardware's order of k: the sum over
-// k pairs the same bytes.
+// k_expand writes the nibbles in MFMA FRAGMENT ORDER, [tile of 32 descriptors][K-step 4][lane = half * 32 + row][16 B]:
+// lane (half, row) of step s holds bits [64 s + 32 half, + 32) of descriptor `row`.  A wave's A or B operand of one K-step
+// is 1 KiB of consecutive memory: query fragments are loaded straight into registers (coalesced), train tiles are copied
+// linearly into LDS and read back conflict-free with ds_read_b128.  The lane -> k mapping inside a fragment is the same
+// for A and B, whatever the hardware's order of k: the sum over k pairs the same bits.
 // ---------------------------------------------------------------------------
 typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int kKnnQT = 2;                  // query tiles (32 queries each) per wave
 constexpr int kKnnWaves = 4;               // waves per workgroup: 256 queries
-constexpr int kTileU4 = 8 * 64;            // uint4 elements of one expanded tile (8 K-steps x 64 lanes)
+constexpr int kTileU4 = 4 * 64;            // uint4 elements of one expanded tile (4 K-steps x 64 lanes = 4 KiB)
+static_assert(64 * kKnnWaves == kKnnQueriesPerBlock, "the host reads the accepted-pair lists in blocks of kKnnQueriesPerBlock queries");
+static_assert(kTileU4 * 16 == 32 * kKnnExpandBytes, "k_expand's tile and the scratch size the engine allocates");
 
-// bit descriptors -> +-64 bytes in fragment order; also gathers the sets a match refers to (setmap) into local order
-// and writes their clamped counts.  One thread per descriptor (two coalesced 16-byte loads, sixteen 16-byte stores that
+// bit descriptors -> e2m1 +-1 nibbles in fragment order; also gathers the sets a match refers to (setmap) into local order
+// and writes their clamped counts.  One thread per descriptor (two coalesced 16-byte loads, eight 16-byte stores that
 // form 512 contiguous bytes across the 32 lanes of a tile); grid (kcap / 256, local sets)
 __global__ __launch_bounds__(256) void k_expand(const uint8_t *__restrict__ desc, const int *__restrict__ counts,
                                                 const int *__restrict__ setmap, int kcap, uint4 *__restrict__ E,
@@ -1478,28 +1489,23 @@ __global__ __launch_bounds__(256) void k_expand(const uint8_t *__restrict__ desc
     const uint32_t w[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     uint4 *out = E + ((size_t)i * (kcap / 32) + (d >> 5)) * kTileU4 + (d & 31);
 #pragma unroll
-    for (int sh = 0; sh < 16; sh++) {                 // K-step * 2 + half: bits [16 sh, 16 sh + 16)
-        const uint32_t bits = (w[sh >> 1] >> (16 * (sh & 1))) & 0xffffu;
+    for (int sh = 0; sh < 8; sh++) {                  // K-step * 2 + half: bits [32 sh, 32 sh + 32)
         uint32_t o[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            // nibble -> four bytes: bit j lands on bit 8j (the four shifted copies do not overlap), then 0x80 / 0x00 -> +64 / -64
-            const uint32_t y = (((bits >> (4 * q)) & 15u) * 0x00204081u) & 0x01010101u;
-            o[q] = (y << 7) ^ 0xC0C0C0C0u;
+            // byte -> eight nibbles: bit j lands on bit 4j, then 1 / 0 -> 0xA (-1.0) / 0x2 (+1.0)
+            uint32_t x = (w[sh] >> (8 * q)) & 0xffu;
+            x = (x | (x << 12)) & 0x000f000fu;
+            x = (x | (x << 6)) & 0x03030303u;
+            x = (x | (x << 3)) & 0x11111111u;
+            o[q] = (x << 3) | 0x22222222u;
         }
         out[(sh >> 1) * 64 + (sh & 1) * 32] = uint4{o[0], o[1], o[2], o[3]};
     }
 }
 
-__device__ __forceinline__ int med3_i32(int a, int b, int c)
-{
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-// kKnnStageTiles: train tiles per LDS stage (8 KiB each), double buffered.  The stages are filled by LDS-DMA
-// (global_load_lds_dwordx4: no staging registers, which keeps the kernel at 4 waves per SIMD).
+// kKnnStageTiles: train tiles per LDS stage (4 KiB each), double buffered.  The stages are filled by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers).
 // 1-D grid, XCD-aware: workgroups b and b + 8 share an XCD, so the query blocks of one (pair, chunk) unit are given ids
 // that are congruent mod 8 -- they stream the same train set and find it in their XCD's L2 after the first has fetched it.
 // FOLD (launches whose train sets fit one chunk, i.e. every full batch): the kernel finishes the job itself -- k-NN rows, the
@@ -1530,34 +1536,36 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
     const int t0 = chunk * chunkLen;
     const int tn = min(nt - t0, chunkLen);              // trains of this chunk
     const int tilesPerSet = kcap / 32;
-    constexpr int kMin = (int)0x80000000;
-    int k0[kKnnQT], k1[kKnnQT];
+    const int ntiles = tn > 0 ? (tn + 31) >> 5 : 0;
+    const float kNone = -__builtin_inff();              // "no key": below every key, unchanged by the per-tile raise
+    float k0[kKnnQT], k1[kKnnQT];                       // running two largest keys, relative to the tile being folded
 #pragma unroll
-    for (int u = 0; u < kKnnQT; u++) k0[u] = k1[u] = kMin;
+    for (int u = 0; u < kKnnQT; u++) k0[u] = k1[u] = kNone;
 
     if (tn > 0) {
-        // query fragments: kKnnQT tiles x 8 K-steps, 1 KiB coalesced loads (tiles past the set's end stay inside the buffer:
+        // query fragments: kKnnQT tiles x 4 K-steps, 1 KiB coalesced loads (tiles past the set's end stay inside the buffer:
         // kcap is a multiple of 64; their columns are never stored)
         const int qtile0 = (qb >> 5) + wave * kKnnQT;
-        v4i Bf[kKnnQT][8];
+        v4i Bf[kKnnQT][4];
 #pragma unroll
         for (int u = 0; u < kKnnQT; u++) {
             const int tq = min(qtile0 + u, tilesPerSet - 1);
             const uint4 *src = E + ((size_t)qt.x * tilesPerSet + tq) * kTileU4 + lane;
 #pragma unroll
-            for (int s = 0; s < 8; s++) Bf[u][s] = __builtin_bit_cast(v4i, src[s * 64]);
+            for (int s = 0; s < 4; s++) Bf[u][s] = __builtin_bit_cast(v4i, src[s * 64]);
         }
-        // ninth K-step, query side: multipliers (1, 64) on k = 0, 1 (lane half 0, bytes 0, 1)
-        // (two k of the step are used: the 16-deep multiply does it in half the matrix-pipe time of a 32-deep one)
-        const long B9 = half == 0 ? 0x4001L : 0L;
-        const uint4 *Et = E + ((size_t)qt.y * tilesPerSet + (t0 >> 5)) * kTileU4;
-        const int nstage = (tn + 32 * kKnnStageTiles - 1) / (32 * kKnnStageTiles);
-        constexpr int kPer = kKnnStageTiles * kTileU4 / (64 * kKnnWaves);   // 1-KiB wave transfers per wave per stage (4)
-        auto fill = [&](int st, int buf) {   // linear copy of the stage, one 1-KiB LDS-DMA per wave and k; tiles wholly past the end are skipped
+        // accumulator input of a tile's first step: 31 - (train row inside the tile); C/D layout: row = (e&3) + 8 (e>>2) + 4 (lane>>5)
+        v16f Crow;
 #pragma unroll
-            for (int k = 0; k < kPer; k++) {
-                const int e0 = k * (64 * kKnnWaves) + wave * 64;            // first element of this wave's transfer
-                if ((st * kKnnStageTiles + e0 / kTileU4) * 32 < tn)
+        for (int e = 0; e < 16; e++) Crow[e] = (float)(31 - ((e & 3) + 8 * (e >> 2) + 4 * half));
+        const uint4 *Et = E + ((size_t)qt.y * tilesPerSet + (t0 >> 5)) * kTileU4;
+        const int nstage = (ntiles + kKnnStageTiles - 1) / kKnnStageTiles;
+        static_assert(kTileU4 == 64 * kKnnWaves, "one LDS-DMA round of the workgroup = one tile (wave w moves K-step w)");
+        auto fill = [&](int st, int buf) {   // linear copy of the stage, one 1-KiB LDS-DMA per wave and tile; tiles wholly past the end are skipped
+#pragma unroll
+            for (int k = 0; k < kKnnStageTiles; k++) {
+                const int e0 = k * kTileU4 + wave * 64;            // first element of this wave's transfer
+                if (st * kKnnStageTiles + k < ntiles)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Et + (size_t)st * kKnnStageTiles * kTileU4 + e0 + lane),
                                                      (__attribute__((address_space(3))) void *)(&stage[buf][e0]), 16, 0, 0);
             }
@@ -1568,106 +1576,112 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
         // The tile loop is software-pipelined: while the matrix pipe multiplies tile t+1 (into a second accumulator set),
         // the vector ALU folds tile t's keys into the running top-2.  A wave issues in order, and a multiply that
         // accumulates into the register of the one two instructions back stalls the wave until that one is done -- so the
-        // top-2 instructions are placed BETWEEN the multiplies in program order (two multiplies, then the eight vector
-        // instructions of four keys; sched_group_barrier keeps the compiler from regrouping them).  Without this the two
-        // pipes took turns: 92 us of MFMA + 75 us of VALU = the 166 us the kernel needed.
-        auto fold1 = [&](int u, int x) {
-            k1[u] = med3_i32(k0[u], k1[u], x);   // second largest of {k0, k1, x} (k0 >= k1)
-            k0[u] = max(k0[u], x);
+        // top-2 instructions are placed BETWEEN the multiplies in program order (two multiplies, then the ten vector
+        // instructions of eight keys; sched_group_barrier keeps the compiler from regrouping them).
+        auto fold2 = [&](int u, float x, float y) {
+            const float t = __builtin_amdgcn_fmed3f(k0[u], x, y);
+            k0[u] = __builtin_fmaxf(__builtin_fmaxf(k0[u], x), y);
+            k1[u] = __builtin_fmaxf(k1[u], t);
         };
-        auto top2 = [&](const v16i (&acc)[kKnnQT]) {
+        auto raise = [&]() {   // the running keys move on to the next tile's frame: its rows are 32 indices further
+#pragma unroll
+            for (int u = 0; u < kKnnQT; u++) { k0[u] += 32.0f; k1[u] += 32.0f; }
+        };
+        auto top2 = [&](const v16f (&acc)[kKnnQT]) {
+            raise();
 #pragma unroll
             for (int u = 0; u < kKnnQT; u++)
 #pragma unroll
-                for (int e = 0; e < 16; e++) fold1(u, acc[u][e]);
+                for (int e = 0; e < 16; e += 2) fold2(u, acc[u][e], acc[u][e + 1]);
         };
-        auto mm_fold = [&](const uint4 *S, int tl, int tb, v16i (&acc)[kKnnQT], const v16i (&old)[kKnnQT]) {
-#pragma unroll
-            for (int u = 0; u < kKnnQT; u++) acc[u] = v16i{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-            // the train fragments are read from LDS two steps ahead of the multiplies that use them: read right in front of
-            // its use, every step began with ~100 cycles of LDS latency (matrix pipe 63 % busy)
+        constexpr int kSc = 0x85858585;   // E8M0 2^6 in every byte: the block scale of both operands
+        auto mm_fold = [&](const uint4 *S, int tb, v16f (&acc)[kKnnQT], const v16f (&old)[kKnnQT]) {
+            raise();
+            // the train fragments are read from LDS two steps ahead of the multiplies that use them
             v4i Af[3];
-            Af[0] = __builtin_bit_cast(v4i, S[(tl * 8) * 64 + lane]);
-            Af[1] = __builtin_bit_cast(v4i, S[(tl * 8 + 1) * 64 + lane]);
+            Af[0] = __builtin_bit_cast(v4i, S[lane]);
+            Af[1] = __builtin_bit_cast(v4i, S[64 + lane]);
 #pragma unroll
-            for (int s = 0; s < 8; s++) {
-                if (s + 2 < 8) Af[(s + 2) % 3] = __builtin_bit_cast(v4i, S[(tl * 8 + s + 2) * 64 + lane]);
-#pragma unroll
-                for (int u = 0; u < kKnnQT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x32_i8(Af[s % 3], Bf[u][s], acc[u], 0, 0, 0);
+            for (int s = 0; s < 4; s++) {
+                if (s + 2 < 4) Af[(s + 2) % 3] = __builtin_bit_cast(v4i, S[(s + 2) * 64 + lane]);
+                const v4i a = Af[s % 3];
+                const v8i A = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
 #pragma unroll
                 for (int u = 0; u < kKnnQT; u++) {
-                    fold1(u, old[u][2 * s]);
-                    fold1(u, old[u][2 * s + 1]);
+                    const v8i B = {Bf[u][s][0], Bf[u][s][1], Bf[u][s][2], Bf[u][s][3], 0, 0, 0, 0};
+                    acc[u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, s == 0 ? Crow : acc[u], 4, 4, 0, kSc, 0, kSc);
                 }
-                if (s + 2 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the ds_read for step s + 2
-                __builtin_amdgcn_sched_group_barrier(0x008, kKnnQT, 0);      // this step's multiplies
-                __builtin_amdgcn_sched_group_barrier(0x002, 4 * kKnnQT, 0);  // four keys' worth of top-2
-            }
-            {   // ninth K-step, train side: 8191 - (index inside the chunk) as two digits of base 64
-                const int iv = 8191 - (tb + (lane & 31));
-                const long A9 = half == 0 ? (long)((iv & 63) | ((iv >> 6) << 8)) : 0L;
 #pragma unroll
-                for (int u = 0; u < kKnnQT; u++) acc[u] = __builtin_amdgcn_mfma_i32_32x32x16_i8(A9, B9, acc[u], 0, 0, 0);
+                for (int u = 0; u < kKnnQT; u++) {
+                    fold2(u, old[u][4 * s], old[u][4 * s + 1]);
+                    fold2(u, old[u][4 * s + 2], old[u][4 * s + 3]);
+                }
+                if (s + 2 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the ds_read for step s + 2
+                __builtin_amdgcn_sched_group_barrier(0x008, kKnnQT, 0);      // this step's multiplies
+                __builtin_amdgcn_sched_group_barrier(0x002, 5 * kKnnQT, 0);  // four keys' worth of top-2 per query tile
             }
-            if (tb + 32 > tn) {   // last tile of the set: rows past the end hold stale bytes
+            // (pins the folds in front of the branch below: nothing else uses their results in this block, and the compiler's
+            // sinking pass moved all forty of them behind it, out of the multiplies' shadow)
+#pragma unroll
+            for (int u = 0; u < kKnnQT; u++) asm volatile("" : "+v"(k0[u]), "+v"(k1[u]));
+            if (tb + 32 > tn) {   // last tile of the set: rows past the end hold stale nibbles
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
-                    const bool ok = tb + (e & 3) + 8 * (e >> 2) + 4 * half < tn;   // C/D layout: row = (e&3) + 8 (e>>2) + 4 (lane>>5)
+                    const bool ok = tb + (e & 3) + 8 * (e >> 2) + 4 * half < tn;
 #pragma unroll
-                    for (int u = 0; u < kKnnQT; u++) acc[u][e] = ok ? acc[u][e] : kMin;
+                    for (int u = 0; u < kKnnQT; u++) acc[u][e] = ok ? acc[u][e] : kNone;
                 }
             }
         };
-        static_assert(kKnnStageTiles == 2, "the pipelined tile loop is written for two tiles per stage");
-        v16i accA[kKnnQT], accB[kKnnQT];
-        const v16i allMin = {kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin, kMin};
+        static_assert(kKnnStageTiles == 4, "the tile loop walks a stage as two pairs of tiles");
+        v16f accA[kKnnQT], accB[kKnnQT];   // even tiles multiply into accB while accA (the odd tile before) is folded, and vice versa
 #pragma unroll
-        for (int u = 0; u < kKnnQT; u++) accA[u] = allMin;   // "nothing pending": folding it changes nothing
-        // (An odd tile count ends in the else branch below, on the last stage.  It used to leave "nothing pending" in accA for
-        // the fold behind the loop: the compiler set those 32 registers in EVERY stage, ahead of the branch -- 18 % of the
-        // loop's vector instructions, in a kernel whose vector issue port is as full as its matrix pipe.  A flag instead.)
-        bool pendingA = true;
-        for (int st = 0; st < nstage; st++) {
-            if (st + 1 < nstage) fill(st + 1, (st + 1) & 1);   // travels while this stage is multiplied (that buffer was last read a barrier ago)
-            const uint4 *S = stage[st & 1];
-            const int tb0 = st * kKnnStageTiles * 32, tb1 = tb0 + 32;   // first trains of the two tiles, relative to t0 (tb0 < tn)
-            mm_fold(S, 0, tb0, accB, accA);
-            if (tb1 < tn) {
-                mm_fold(S, 1, tb1, accA, accB);
-            } else {
-                top2(accB);
-                pendingA = false;   // (st is the last stage: tb1 >= tn)
+        for (int u = 0; u < kKnnQT; u++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) accA[u][e] = kNone;   // "nothing pending": folding it changes nothing
+        const int npr = (ntiles + 1) >> 1;
+#pragma unroll 1
+        for (int pr = 0; pr < npr; pr++) {   // two tiles per trip; a stage is two trips
+            const int st = pr >> 1;
+            if (!(pr & 1) && st + 1 < nstage) fill(st + 1, (st + 1) & 1);   // travels while this stage is multiplied (that buffer was last read a barrier ago)
+            const uint4 *S = stage[st & 1] + (pr & 1) * 2 * kTileU4;
+            const int tb0 = pr * 64, tb1 = tb0 + 32;   // first trains of the two tiles, relative to t0 (tb0 < tn)
+            mm_fold(S, tb0, accB, accA);
+            if (tb1 < tn) mm_fold(S + kTileU4, tb1, accA, accB);
+            if (pr & 1) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next stage has landed
+                __syncthreads();
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next stage has landed
-            __syncthreads();
         }
-        if (pendingA) top2(accA);
+        if (ntiles & 1) top2(accB); else top2(accA);           // the last tile's keys are still pending
     }
     // the two lane halves hold different train rows of the same query columns: merge, convert, store
-    auto conv = [&](int key) -> uint32_t {
-        if (key == kMin) return 0xffffffffu;
-        const uint32_t kp = (uint32_t)(key + (1 << 20));            // 8192 * (256 - hamming) + (8191 - index)
+    const int koff = 8160 - 32 * (ntiles - 1) + (1 << 20);     // tile frame of the last tile -> global key, + 2^20: non-negative
+    auto conv = [&](float key) -> uint32_t {
+        if (key == kNone) return 0xffffffffu;
+        const uint32_t kp = (uint32_t)((int)key + koff);            // 8192 * (256 - hamming) + (8191 - index)
         return ((256u - (kp >> 13)) << 16) | (uint32_t)(t0 + 8191 - (int)(kp & 8191u));
     };
     if (!FOLD) {
         uint2 *out = part + ((size_t)pair * nchunks + chunk) * kcap;
 #pragma unroll
         for (int u = 0; u < kKnnQT; u++) {
-            const int o0 = __shfl_xor(k0[u], 32), o1 = __shfl_xor(k1[u], 32);
-            const int m0 = max(k0[u], o0), m1 = max(min(k0[u], o0), max(k1[u], o1));
+            const float o0 = __shfl_xor(k0[u], 32), o1 = __shfl_xor(k1[u], 32);
+            const float m0 = fmaxf(k0[u], o0), m1 = fmaxf(fminf(k0[u], o0), fmaxf(k1[u], o1));
             const int q = qb + (wave * kKnnQT + u) * 32 + (lane & 31);
             if (half == 0 && q < nq) out[q] = uint2{conv(m0), conv(m1)};
         }
         return;
     }
     // folded finalize (k_knn2_finalize's statements on this workgroup's 256 queries): rows, accept flag, compaction in query order
-    int *wcnt = reinterpret_cast<int *>(&stage[0][0]);   // (the stages are idle: every wave is past the loop's last barrier)
+    __syncthreads();                                     // every wave has read its last tile: the stages are idle
+    int *wcnt = reinterpret_cast<int *>(&stage[0][0]);
     uint32_t packed[kKnnQT];
     unsigned long long bal[kKnnQT];
 #pragma unroll
     for (int u = 0; u < kKnnQT; u++) {
-        const int o0 = __shfl_xor(k0[u], 32), o1 = __shfl_xor(k1[u], 32);
-        const int m0 = max(k0[u], o0), m1 = max(min(k0[u], o0), max(k1[u], o1));
+        const float o0 = __shfl_xor(k0[u], 32), o1 = __shfl_xor(k1[u], 32);
+        const float m0 = fmaxf(k0[u], o0), m1 = fmaxf(fminf(k0[u], o0), fmaxf(k1[u], o1));
         const int q = qb + (wave * kKnnQT + u) * 32 + (lane & 31);
         const uint32_t c0 = conv(m0), c1 = conv(m1);
         const bool v0 = c0 != 0xffffffffu, v1 = c1 != 0xffffffffu;
@@ -2025,12 +2039,12 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
     dim3 grid(8 * qblocks * ((units + 7) / 8));
     // 130 VGPRs: 3 waves per SIMD.  (Capping at 128 for 4 waves spills one query fragment into scratch: 177 vs 162 us.)
     if (nchunks == 1) {
-        hipLaunchKernelGGL((k_knn2<2, 3, true>), grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, npairs, qblocks, part, chunkLen,
+        hipLaunchKernelGGL((k_knn2<4, 3, true>), grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, npairs, qblocks, part, chunkLen,
                            dist_thresh, ratio, out, mlist, mcount);
         if (ev_mid) (void)hipEventRecord(ev_mid, st);
         return;
     }
-    hipLaunchKernelGGL((k_knn2<2, 3, false>), grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, npairs, qblocks, part, chunkLen,
+    hipLaunchKernelGGL((k_knn2<4, 3, false>), grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, npairs, qblocks, part, chunkLen,
                        dist_thresh, ratio, out, mlist, mcount);
     if (ev_mid) (void)hipEventRecord(ev_mid, st);
     hipLaunchKernelGGL(k_knn2_finalize, dim3(npairs), dim3(1024), 0, st, part, lcounts, pairs, kcap, nchunks, chunkLen, dist_thresh, ratio, out, mlist,
