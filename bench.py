@@ -96,6 +96,68 @@ def cpu_baseline(cfg, frames, threads):
     return np.array(times), np.array(t_extract), results
 
 
+def free_port():
+    """a TCP port nobody listens on right now (bind to 0, read it back): two sessions on one box do not collide on a fixed one"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` typed without a launcher: this process -- before it has touched torch or the GPU, and without
+    exec -- starts the N ranks itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, same arguments), relays
+    rank 0's JSON line and exits non-zero if any rank does."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.readlines()))
+    reader.start()
+    rcs = [None] * n
+    failed_at = None
+    while any(rc is None for rc in rcs):
+        for r, pr in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = pr.poll()
+        if failed_at is None and any(rc not in (None, 0) for rc in rcs):
+            failed_at = time.time()                      # a rank died: the others are stuck in a collective
+        if failed_at is not None and time.time() - failed_at > 20:
+            for r, pr in enumerate(procs):
+                if rcs[r] is None:
+                    pr.kill()                            # (exactly the processes this function started)
+        time.sleep(0.2)
+    reader.join()
+    for line in out0:
+        sys.stdout.write(line)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed: %s\n" % bad)
+        return 1
+    return 0
+
+
+def child_value(extra, timeout=600):
+    """one more bench line from a fresh child process (own HIP / RCCL state); returns its parsed JSON or {"error": ...}"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--no-cpu", "--no-latency", "--no-staging", "--host-cores", "0", "--no-extra-legs"] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        pr = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": "timeout"}
+    lines = [l for l in pr.stdout.splitlines() if l.startswith("{")]
+    if pr.returncode != 0 or not lines:
+        return {"error": "rc %d: %s" % (pr.returncode, pr.stderr[-300:])}
+    return json.loads(lines[-1])
+
+
 def kernels_sha():
     return hashlib.sha256(open(os.path.join(ROOT, "mc-slam_amd", "csrc", "mcorb_kernels.hip"), "rb").read()).hexdigest()[:16]
 
@@ -132,7 +194,30 @@ def main():
                     help="N > 1: frames = frame f matched on rank f mod N; pairs = camera pair (i, j) of frame f matched on rank "
                          "(i + j + f) mod N, the accepted lists gathered on rank 0, which runs the serial track merge")
     ap.add_argument("--dump-tracks", default=None, help="(tests) write the tracks of this rank's first frames to an .npz")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="skip the two child-process legs of the N = 1 line: value_force_dist (the sharded path at world size 1, the "
+                         "like-for-like denominator of value(N) / (N value(1))) and configs2_1080p8 (BASELINE configs[2] on one GPU)")
+    ap.add_argument("--spawn-selftest", type=int, default=None, metavar="FAIL_RANK",
+                    help="(tests, no GPU) the ranks only rendezvous over gloo, all-reduce their rank numbers and rank 0 prints "
+                         "what it saw; rank FAIL_RANK (>= 0) exits with status 3 instead")
     args = ap.parse_args()
+    if args.spawn_selftest is not None and "RANK" in os.environ:
+        rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+        if rank == args.spawn_selftest:
+            sys.exit(3)
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([rank + 1.0])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"ranks_seen": dist.get_world_size(), "backend": dist.get_backend(), "sum": float(t.item()), "n_gpus": args.gpus}), flush=True)
+        dist.destroy_process_group()
+        return
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # typed the way the driver types `--gpus 1`: no launcher around it.  Start the ranks from here (no GPU call, no torch
+        # import, no exec before this point) and relay rank 0's line.
+        sys.exit(spawn_ranks(args.gpus))
     cfg = CONFIGS[args.config]
     W, H, NCAMS, NFEAT = cfg["W"], cfg["H"], cfg["NCAMS"], cfg["NFEAT"]
 
@@ -154,7 +239,7 @@ def main():
     if DIST:
         import torch.distributed as dist
         if args.force_dist and "RANK" not in os.environ:
-            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29555")
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()))
         if gloo:
             dist.init_process_group("gloo")
         else:
@@ -591,7 +676,8 @@ def main():
                                    "evidence": "profiles/r03_valu_rates.txt (tools/valu_rates.hip, 1/2/4/8 waves per SIMD)"}
     if DIST:
         out["exchange"] = {"collective": "all_gather_into_tensor + gather of the pair tables to rank 0" if PAIRS else "all_to_all_single (uneven splits)", "bytes_sent_per_rank_per_step": int(exchange_bytes * IT), "rounds_per_step": IT,
-                           "send_splits_rank0": None if PAIRS else send_splits}
+                           "send_splits_rank0": None if PAIRS else send_splits,
+                           "ranks_seen": dist.get_world_size(), "backend": dist.get_backend()}
     if iso:
         ia = unit_bytes * units / (iso[dominant] * 1e-6) / 1e9
         out["roofline"].update({"isolated_launch_us": round(iso[dominant], 2), "isolated_achieved": round(ia, 2),
@@ -679,6 +765,19 @@ def main():
         from latency import measure
         lat = measure(mcorb, NCAMS, W, H, NFEAT, frames=100)
         out["single_frame_latency_ms"] = {k: lat[k] for k in ("upload_ms", "extract_match_ms", "readback_ms", "total_ms", "total_p95_ms")}
+    if N == 1 and not DIST and not args.no_extra_legs and args.config == "720p4":
+        # two more driver-visible numbers, each from a fresh child process after this one's legs are done (its rig is closed):
+        rig.close()
+        fd = child_value(["--force-dist", "--repeats", "1"])
+        out["value_force_dist"] = ({"value": fd["value"], "sharding": fd["config"]["sharding"], "exchange": fd.get("exchange"),
+                                    "note": "the N > 1 code path (export -> RCCL all-to-all -> external match) at world size 1, same steps: the "
+                                            "like-for-like denominator for value(N) / (N value(1)); `value` itself runs the fused path"}
+                                   if "value" in fd else fd)
+        c2 = child_value(["--config", "1080p8", "--repeats", "1"])
+        out["configs2_1080p8"] = ({"value": c2["value"], "unit": c2["unit"], "ms_per_frame": c2["ms_per_frame"], "workload": c2["config"]["workload"],
+                                   "frames_per_launch": c2["config"]["frames_per_launch"], "steps": c2["steps"],
+                                   "note": "BASELINE configs[2] (8 cameras, 1920x1080, 28 camera pairs per rig frame) on ONE GPU; at --gpus 8 it is one camera per GPU"}
+                                  if "value" in c2 else c2)
     print(json.dumps(out), flush=True)
     rig.close()
     if dist is not None:

@@ -212,6 +212,8 @@ int mcorb_rig_match_external_dev_submit(mcorb_rig *r, int slot, const void *desc
  * (images per slot) distinct sets and ncams (ncams - 1) / 2 x (frames per slot) pairs per job; no tracks are built
  * (mcorb_rig_get_tracks fails), the lists are read with mcorb_rig_get_pairlist (pair = index into pair_sets).  The _dev_submit
  * form orders the job behind `after_stream` like mcorb_rig_match_external_dev_submit; wait with mcorb_rig_match_wait.
+ * LIFETIME: the submit forms return before the slot's driver thread has read `sets` / `pair_sets` (and the host `counts` of the
+ * non-_dev forms): those arrays must stay valid and unchanged until mcorb_rig_match_wait has returned for that slot.
  * mcorb_host_merge_tracks: the merge itself on caller-supplied lists (pairs in (0,1), (0,2), .., (1,2), .. order, npair[p]
  * entries each, counts[c] keypoints per camera) -> tracks [n][ncams], -1 = absent; no device involved. */
 int mcorb_rig_match_pairs_external(mcorb_rig *r, int slot, const void *desc_dev, const int32_t *counts, int ntotal,

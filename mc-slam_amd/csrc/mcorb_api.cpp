@@ -567,12 +567,14 @@ int mcorb_host_merge_tracks(int ncams, const int32_t *counts, const uint32_t *co
     if (mergeable_out) *mergeable_out = 0;
     if (ncams < 2 || ncams > MCORB_MAX_CAMS || !counts || !idx1 || !idx2 || !npair) { set_error("merge_tracks: bad argument"); return MCORB_E_ARG; }
     const int npairs = ncams * (ncams - 1) / 2;
+    for (int c = 0; c < ncams; c++)
+        if (counts[c] < 0) { set_error("merge_tracks: negative keypoint count"); return MCORB_E_ARG; }
     int pl = 0;
     for (int a = 0; a < ncams - 1; a++)
         for (int b = a + 1; b < ncams; b++, pl++) {
             if (npair[pl] < 0 || (npair[pl] && (!idx1[pl] || !idx2[pl]))) { set_error("merge_tracks: bad pair list"); return MCORB_E_ARG; }
             for (int k = 0; k < npair[pl]; k++)
-                if ((int)idx1[pl][k] >= counts[a] || (int)idx2[pl][k] >= counts[b]) { set_error("merge_tracks: index beyond the camera's keypoint count"); return MCORB_E_ARG; }
+                if (idx1[pl][k] >= (uint32_t)counts[a] || idx2[pl][k] >= (uint32_t)counts[b]) { /* unsigned: 0x80000000 is not a negative index */ set_error("merge_tracks: index beyond the camera's keypoint count"); return MCORB_E_ARG; }
         }
     (void)npairs;
     std::vector<int32_t> tr;
@@ -875,6 +877,7 @@ int mcorb_host_select(const uint32_t *packed, int n, int minX, int maxX, int min
     std::vector<int> out((size_t)std::max(nfeatures_level, 0) + 64 + 8);
     std::vector<uint32_t> outv(out.size());
     const int r = select_octree(sorted.data(), bstart.data(), bbest.data(), n, P, out.data(), outv.data(), sc);
+    if (r == -4) { set_error("host_select: 2^20 candidates or a level 4096 px wide: beyond the packed (count, UL.x) sort key"); return MCORB_E_SIZE; }
     if (r < 0) { set_error("host_select: level too tall"); return MCORB_E_SIZE; }
     if (r > cap) { set_error("host_select: output too small"); return MCORB_E_CAP; }
     for (int i = 0; i < r; i++) {

@@ -814,7 +814,8 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
     // small copies around 250 us of kernels.  For small batches the three copies go: k_compact writes its tables straight into the
     // host-mapped h_tbl, the describe / k-NN kernels read the control block from host-mapped h_ctrl, k_describe_fused writes the
     // host's descriptor copy itself (a few hundred KB over PCIe in all).
-    s.small_job = j.nimg <= kSmallBatch && params.orientation == 0 && !blur_planes;
+    static const bool side = getenv("MCORB_COMPACT_SIDE") != nullptr;   // round-1 placement of k_compact, for comparison
+    s.small_job = j.nimg <= kSmallBatch && params.orientation == 0 && !blur_planes && !side;   // (the knob keeps the copy path: it must not select half of each)
     s.h_overflow[0] = 0;
     HIPCHK(hipEventRecord(s.ev[0], s.st));
     launch_pyramid(s.st, s.d_pyr, geom, d_taps, resize_win, j.nimg);
@@ -823,11 +824,10 @@ int Rig::run_extract_phaseA(Slot &s, const Job &j)
     HIPCHK(hipEventRecord(s.ev[2], s.st));
     // compaction fills the per-image table blocks in device memory (a short kernel: it runs on the compute stream, ahead
     // of whatever comes next); the DMA that takes the blocks to the host runs on the side stream.
-    static const bool side = getenv("MCORB_COMPACT_SIDE") != nullptr;   // round-1 placement, for comparison
     if (side) HIPCHK(hipStreamWaitEvent(s.st_copy, s.ev[2], 0));
     launch_compact(side ? s.st_copy : s.st, s.d_cellkp, s.d_cellcnt, geom, d_lut, s.d_sorted, s.h_cand, s.small_job ? s.h_tbl : s.d_tbl, s.h_overflow, j.nimg);
     HIPCHK(hipEventRecord(s.ev_c, side ? s.st_copy : s.st));
-    if (s.small_job && !side) {
+    if (s.small_job) {
         HIPCHK(hipEventRecord(s.ev[3], s.st));   // the tables are in host memory when k_compact is done
         s.blur_valid = false;
         HIPCHK(hipEventRecord(s.ev[4], s.st));

@@ -1468,7 +1468,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr int kKnnQT = 2;                  // query tiles (32 queries each) per wave
 constexpr int kKnnWaves = 4;               // waves per workgroup: 256 queries
 constexpr int kTileU4 = 4 * 64;            // uint4 elements of one expanded tile (4 K-steps x 64 lanes = 4 KiB)
-static_assert(64 * kKnnWaves == kKnnQueriesPerBlock, "the host reads the accepted-pair lists in blocks of kKnnQueriesPerBlock queries");
+static_assert(32 * kKnnQT * kKnnWaves == kKnnQueriesPerBlock, "the host reads the accepted-pair lists in blocks of kKnnQueriesPerBlock queries");
 static_assert(kTileU4 * 16 == 32 * kKnnExpandBytes, "k_expand's tile and the scratch size the engine allocates");
 
 // bit descriptors -> e2m1 +-1 nibbles in fragment order; also gathers the sets a match refers to (setmap) into local order
@@ -1512,14 +1512,15 @@ __global__ __launch_bounds__(256) void k_expand(const uint8_t *__restrict__ desc
 // BruteForceMatch accept test and the accepted pairs compacted per 256-query block (mlist[pair][block * 256 + k], count in
 // mcount[pair * qblocks + block]; blocks are in query order, so the host concatenates them) -- instead of writing partials
 // for k_knn2_finalize: one launch, a 23-us kernel and a partial-table round trip less per batch.
-template <int kKnnStageTiles, int kWavesPerSimd, bool FOLD>
+template <int kKnnStageTiles, int kWavesPerSimd, bool FOLD, int DBG = 0>
 __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const uint4 *__restrict__ E, const int *__restrict__ lcounts,
                                                            const int2 *__restrict__ pairs, int kcap, int nchunks, int npairs,
                                                            int qblocks, uint2 *__restrict__ part, int chunkLen,
                                                            float dist_thresh, float ratio, KnnRow *__restrict__ rows,
                                                            uint32_t *__restrict__ mlist, int *__restrict__ mcount)
 {
-    __shared__ __attribute__((aligned(16))) uint4 stage[2][kKnnStageTiles * kTileU4];
+    // (+ two fragments of slack: the tile loop reads two steps ahead, at a stage's last tile past its end)
+    __shared__ __attribute__((aligned(16))) uint4 stage[2 * kKnnStageTiles * kTileU4 + 2 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int slot = blockIdx.x >> 3, grp = slot / qblocks;
     const int unit = grp * 8 + (blockIdx.x & 7);        // (pair, chunk) unit
@@ -1528,7 +1529,7 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
     const int2 qt = pairs[pair];
     const int nq = lcounts[qt.x], nt = lcounts[qt.y];
     const int qbi = slot - grp * qblocks;
-    const int qb = qbi * (64 * kKnnWaves);   // first query of the workgroup
+    const int qb = qbi * kKnnQueriesPerBlock;   // first query of the workgroup
     if (qb >= nq) {
         if (FOLD && tid == 0) mcount[pair * qblocks + qbi] = 0;
         return;
@@ -1567,7 +1568,7 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
                 const int e0 = k * kTileU4 + wave * 64;            // first element of this wave's transfer
                 if (st * kKnnStageTiles + k < ntiles)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Et + (size_t)st * kKnnStageTiles * kTileU4 + e0 + lane),
-                                                     (__attribute__((address_space(3))) void *)(&stage[buf][e0]), 16, 0, 0);
+                                                     (__attribute__((address_space(3))) void *)(&stage[buf * kKnnStageTiles * kTileU4 + e0]), 16, 0, 0);
             }
         };
         fill(0, 0);
@@ -1595,16 +1596,17 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
                 for (int e = 0; e < 16; e += 2) fold2(u, acc[u][e], acc[u][e + 1]);
         };
         constexpr int kSc = 0x85858585;   // E8M0 2^6 in every byte: the block scale of both operands
-        auto mm_fold = [&](const uint4 *S, int tb, v16f (&acc)[kKnnQT], const v16f (&old)[kKnnQT]) {
+        // Train fragments travel LDS -> registers two K-steps ahead of the multiplies that use them, through a ring of four that
+        // runs on across the tiles of a stage (a pair of tiles is eight steps: the ring index of a step is a constant): a wave
+        // waits for LDS once per stage, not once per tile.
+        v4i Af[4];
+        auto tile = [&](const int base, const uint4 *S, int tb, v16f (&acc)[kKnnQT], const v16f (&old)[kKnnQT]) {   // S: the PAIR's first tile; base = 0 / 4
             raise();
-            // the train fragments are read from LDS two steps ahead of the multiplies that use them
-            v4i Af[3];
-            Af[0] = __builtin_bit_cast(v4i, S[lane]);
-            Af[1] = __builtin_bit_cast(v4i, S[64 + lane]);
 #pragma unroll
             for (int s = 0; s < 4; s++) {
-                if (s + 2 < 4) Af[(s + 2) % 3] = __builtin_bit_cast(v4i, S[(s + 2) * 64 + lane]);
-                const v4i a = Af[s % 3];
+                const int g = base + s;
+                Af[(g + 2) & 3] = __builtin_bit_cast(v4i, S[(g + 2) * 64 + lane]);   // (steps 8, 9: the next pair's first two)
+                const v4i a = Af[g & 3];
                 const v8i A = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
 #pragma unroll
                 for (int u = 0; u < kKnnQT; u++) {
@@ -1613,15 +1615,16 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
                 }
 #pragma unroll
                 for (int u = 0; u < kKnnQT; u++) {
+                    if (DBG & 4) { if (s == 0) fold2(u, old[u][0], old[u][15]); continue; }
                     fold2(u, old[u][4 * s], old[u][4 * s + 1]);
                     fold2(u, old[u][4 * s + 2], old[u][4 * s + 3]);
                 }
-                if (s + 2 < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // the ds_read for step s + 2
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // the ds_read for step g + 2
                 __builtin_amdgcn_sched_group_barrier(0x008, kKnnQT, 0);      // this step's multiplies
                 __builtin_amdgcn_sched_group_barrier(0x002, 5 * kKnnQT, 0);  // four keys' worth of top-2 per query tile
             }
             // (pins the folds in front of the branch below: nothing else uses their results in this block, and the compiler's
-            // sinking pass moved all forty of them behind it, out of the multiplies' shadow)
+            // sinking pass moved all of them behind it, out of the multiplies' shadow)
 #pragma unroll
             for (int u = 0; u < kKnnQT; u++) asm volatile("" : "+v"(k0[u]), "+v"(k1[u]));
             if (tb + 32 > tn) {   // last tile of the set: rows past the end hold stale nibbles
@@ -1633,24 +1636,28 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
                 }
             }
         };
-        static_assert(kKnnStageTiles == 4, "the tile loop walks a stage as two pairs of tiles");
+        static_assert(kKnnStageTiles % 2 == 0, "the tile loop walks a stage as pairs of tiles");
         v16f accA[kKnnQT], accB[kKnnQT];   // even tiles multiply into accB while accA (the odd tile before) is folded, and vice versa
 #pragma unroll
         for (int u = 0; u < kKnnQT; u++)
 #pragma unroll
             for (int e = 0; e < 16; e++) accA[u][e] = kNone;   // "nothing pending": folding it changes nothing
-        const int npr = (ntiles + 1) >> 1;
+        for (int st = 0; st < nstage; st++) {
+            if (!(DBG & 1) && st + 1 < nstage) fill(st + 1, (st + 1) & 1);   // travels while this stage is multiplied (that buffer was last read a barrier ago)
+            const uint4 *Sst = stage + (st & 1) * kKnnStageTiles * kTileU4;
+            Af[0] = __builtin_bit_cast(v4i, Sst[lane]);
+            Af[1] = __builtin_bit_cast(v4i, Sst[64 + lane]);
+            const int tcount = min(ntiles - st * kKnnStageTiles, kKnnStageTiles);   // tiles of this stage
 #pragma unroll 1
-        for (int pr = 0; pr < npr; pr++) {   // two tiles per trip; a stage is two trips
-            const int st = pr >> 1;
-            if (!(pr & 1) && st + 1 < nstage) fill(st + 1, (st + 1) & 1);   // travels while this stage is multiplied (that buffer was last read a barrier ago)
-            const uint4 *S = stage[st & 1] + (pr & 1) * 2 * kTileU4;
-            const int tb0 = pr * 64, tb1 = tb0 + 32;   // first trains of the two tiles, relative to t0 (tb0 < tn)
-            mm_fold(S, tb0, accB, accA);
-            if (tb1 < tn) mm_fold(S + kTileU4, tb1, accA, accB);
-            if (pr & 1) {
+            for (int pr = 0; 2 * pr < tcount; pr++) {   // two tiles per trip
+                const uint4 *S = Sst + pr * 2 * kTileU4;
+                const int tb0 = (st * kKnnStageTiles + 2 * pr) * 32;   // first train of the pair, relative to t0
+                tile(0, S, tb0, accB, accA);
+                if (2 * pr + 1 < tcount) tile(4, S, tb0 + 32, accA, accB);
+            }
+            if (!(DBG & 1)) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next stage has landed
-                __syncthreads();
+                if (!(DBG & 16)) __syncthreads();
             }
         }
         if (ntiles & 1) top2(accB); else top2(accA);           // the last tile's keys are still pending
@@ -1675,7 +1682,7 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
     }
     // folded finalize (k_knn2_finalize's statements on this workgroup's 256 queries): rows, accept flag, compaction in query order
     __syncthreads();                                     // every wave has read its last tile: the stages are idle
-    int *wcnt = reinterpret_cast<int *>(&stage[0][0]);
+    int *wcnt = reinterpret_cast<int *>(&stage[0]);
     uint32_t packed[kKnnQT];
     unsigned long long bal[kKnnQT];
 #pragma unroll
@@ -1691,6 +1698,7 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
             const float f0 = (float)d0, f1 = (float)d1;   // DMatch::distance is float
             acc = (f0 < __fmul_rn(ratio, f1)) && !(f0 > dist_thresh);
         }
+        if (DBG) acc = 0;   // (timing variants compute garbage: nothing is accepted, the host sees empty lists)
         const bool mine = half == 0 && q < nq;
         if (mine) {
             KnnRow r;
@@ -1708,7 +1716,7 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
     __syncthreads();
     int before = 0;
     for (int i = 0; i < wave * kKnnQT; i++) before += wcnt[i];
-    uint32_t *ml = mlist + (size_t)pair * (qblocks * 64 * kKnnWaves) + qb;
+    uint32_t *ml = mlist + (size_t)pair * (qblocks * kKnnQueriesPerBlock) + qb;
 #pragma unroll
     for (int u = 0; u < kKnnQT; u++) {
         if ((bal[u] >> lane) & 1) ml[lane_rank(bal[u], before)] = packed[u];
@@ -1769,7 +1777,7 @@ __global__ __launch_bounds__(1024) void k_knn2_finalize(const uint2 *__restrict_
         __syncthreads();
         int before = s_run;
         for (int w = 0; w < wave; w++) before += wsum[w];
-        if (acc) mlist[(size_t)pair * (qblocks * 64 * kKnnWaves) + lane_rank(b, before)] = ((uint32_t)q << 16) | t0;
+        if (acc) mlist[(size_t)pair * (qblocks * kKnnQueriesPerBlock) + lane_rank(b, before)] = ((uint32_t)q << 16) | t0;
         __syncthreads();
         if (tid == 0) {
             int tot = 0;
@@ -2035,9 +2043,13 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
     hipLaunchKernelGGL(k_expand, dim3((kcap + 255) / 256, nsets), dim3(256), 0, st, desc, counts, setmap, kcap, E, lcounts);
     if (ev_exp) (void)hipEventRecord(ev_exp, st);
     const int chunkLen = knn_chunk_len(npairs), nchunks = (kcap + chunkLen - 1) / chunkLen;
-    const int qblocks = (kcap + 64 * kKnnWaves - 1) / (64 * kKnnWaves), units = npairs * nchunks;
+    const int qblocks = knn_qblocks(kcap), units = npairs * nchunks;
     dim3 grid(8 * qblocks * ((units + 7) / 8));
     // 130 VGPRs: 3 waves per SIMD.  (Capping at 128 for 4 waves spills one query fragment into scratch: 177 vs 162 us.)
+    static const int dbg = getenv("MCORB_KNN_DBG") ? atoi(getenv("MCORB_KNN_DBG")) : 0;   // timing experiments only (scripts/knn_dbg.sh): results are wrong
+    // bit 0: no LDS fill, no barrier; bit 2: no top-2 folds; bit 4: fill, but no barrier
+#define MCORB_KNN_DBG_LAUNCH(D_) if (dbg == D_) { hipLaunchKernelGGL((k_knn2<4, 3, true, D_>), grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, npairs, qblocks, part, chunkLen, dist_thresh, ratio, out, mlist, mcount); if (ev_mid) (void)hipEventRecord(ev_mid, st); return; }
+    if (nchunks == 1 && dbg) { MCORB_KNN_DBG_LAUNCH(1) MCORB_KNN_DBG_LAUNCH(4) MCORB_KNN_DBG_LAUNCH(5) MCORB_KNN_DBG_LAUNCH(16) }
     if (nchunks == 1) {
         hipLaunchKernelGGL((k_knn2<4, 3, true>), grid, dim3(64 * kKnnWaves), 0, st, E, lcounts, pairs, kcap, nchunks, npairs, qblocks, part, chunkLen,
                            dist_thresh, ratio, out, mlist, mcount);

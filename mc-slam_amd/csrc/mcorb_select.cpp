@@ -135,6 +135,9 @@ int select_octree(const uint32_t *cand, const int *bstart, const BB *bbest, int 
     const int N = P.N, D = P.depth;
     if (P.nIni < 1) return -2;
     if (n <= 0) return 0;
+    // the sort key packs (key count << 12 | UL.x) into 32 bits: counts below 2^20, level widths below 4096 (the rig geometry's
+    // limit); anything larger would silently reorder compareNodes' ties
+    if (n >= (1 << 20) || P.maxX - P.minX >= 4096) return -4;
     const float hX = P.hX;
 
     // root nodes (:567-578); their key sets are the top-level bucket ranges

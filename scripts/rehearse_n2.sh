@@ -6,9 +6,9 @@
 O=gpurun_out/${1:-n2}; mkdir -p $O
 COMMON="--steps 2 --warmup 1 --repeats 1 --min-region-s 0 --no-cpu --no-latency --no-staging --host-cores 0 --iso-jobs 1"
 python bench.py $COMMON --frames 16 --slots 1 --dump-tracks $O/fused.npz > $O/fused.json 2>$O/fused.err || { tail -3 $O/fused.err; exit 1; }
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29711 bench.py --gpus 2 --single-device \
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $(python3 -c 'import socket; s=socket.socket(); s.bind(("127.0.0.1",0)); print(s.getsockname()[1])') bench.py --gpus 2 --single-device \
     --dist-backend gloo $COMMON --frames 8 --slots 4 --dump-tracks $O/a2a.npz > $O/a2a.json 2>$O/a2a.err || { tail -5 $O/a2a.err; exit 1; }
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29713 bench.py --gpus 2 --single-device \
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $(python3 -c 'import socket; s=socket.socket(); s.bind(("127.0.0.1",0)); print(s.getsockname()[1])') bench.py --gpus 2 --single-device \
     --dist-backend gloo --exchange allgather --partition pairs $COMMON --frames 8 --slots 2 --dump-tracks $O/pairs.npz > $O/pairs.json 2>$O/pairs.err || { tail -5 $O/pairs.err; exit 1; }
 python3 - <<PY
 import numpy as np, json

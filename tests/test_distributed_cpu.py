@@ -24,6 +24,14 @@ def _extract(f, c):
     return d
 
 
+def _free_port():
+    """bind to port 0 and read it back: two test sessions on one box do not collide (advisor finding, round 3)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def _worker_a2a(rank, world, port, q):
     """the exchange bench.py uses: every set goes only to the rank that matches its frame (uneven all-to-all)"""
     sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -154,7 +162,7 @@ def test_sharded_pipeline_equals_single_process(world, worker):
     import oracle_lib as O
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + {"allgather": 0, "a2a": 7, "pairs": 13}[worker]
+    port = _free_port()
     target = {"allgather": _worker, "a2a": _worker_a2a, "pairs": _worker_pairs}[worker]
     procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
@@ -243,3 +251,19 @@ def test_pair_partition_placement(world, ncams, fpr):
     per = [len(shard.pairs_of_rank(r, world, ncams, total)) for r in range(world)]
     assert max(per) - min(per) <= 0 if total % world == 0 else True
     assert [shard.pair_slot(ncams, i, j) for i in range(ncams - 1) for j in range(i + 1, ncams)] == list(range(ncams * (ncams - 1) // 2))
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2`, typed the way the driver types `--gpus 1`: the parent spawns the ranks itself (before any
+    GPU call), they rendezvous (gloo here: no GPU in this container), rank 0's line is relayed, and a failing rank makes the
+    parent exit non-zero."""
+    import json
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, bench, "--gpus", "2", "--spawn-selftest", "-1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["ranks_seen"] == 2 and line["sum"] == 3.0 and line["backend"] == "gloo" and line["n_gpus"] == 2
+    p = subprocess.run([sys.executable, bench, "--gpus", "2", "--spawn-selftest", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "ranks failed" in p.stderr

@@ -531,7 +531,7 @@ def test_bench_sharded_path_in_a_fresh_process(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29671", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")   # (--force-dist picks a free port itself)
     outs = {}
     for name, extra in (("dist", ["--force-dist"]), ("fused", [])):
         dump = str(tmp_path / (name + ".npz"))
@@ -558,7 +558,7 @@ def test_bench_pair_partitioned_path_in_a_fresh_process(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29673", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")   # (--force-dist picks a free port itself)
     outs = {}
     for name, extra in (("pairs", ["--force-dist", "--exchange", "allgather", "--partition", "pairs", "--slots", "2"]), ("fused", ["--slots", "1"])):
         dump = str(tmp_path / (name + ".npz"))

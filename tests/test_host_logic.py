@@ -134,6 +134,32 @@ def test_selection_edge_cases():
     assert L.mcorb_host_select(p.ctypes.data, 1, 16, 116, 16, 416, 10, 0, 0, out.ctypes.data, 8) == _lib.E_SIZE
 
 
+def test_selection_rejects_sizes_beyond_the_packed_sort_key():
+    """the host stage packs compareNodes' (key count, UL.x) into 32 bits (20 + 12): a level 4096 px wide would silently reorder
+    ties -- it is refused instead (advisor finding, round 3)"""
+    x = np.array([5, 4100], np.int32); y = np.array([7, 9], np.int32); r = np.array([30, 40], np.int32)
+    out = np.zeros(80, np.int32)
+    p = _pack(x, y, r)
+    assert L.mcorb_host_select(p.ctypes.data, 2, 16, 16 + 4096, 16, 16 + 4000, 10, 0, 0, out.ctypes.data, 80) == _lib.E_SIZE
+    assert L.mcorb_host_select(p.ctypes.data, 1, 16, 16 + 4095, 16, 16 + 4000, 10, 0, 0, out.ctypes.data, 80) == 1
+
+
+def test_merge_tracks_bounds_check_is_unsigned():
+    """an index of 0x80000000 in a gathered pair list is out of range, not negative (advisor finding, round 3)"""
+    import ctypes as C
+    counts = np.array([4, 4], np.int32)
+    i1 = np.array([0x80000000], np.uint32); i2 = np.array([1], np.uint32)
+    p1, p2 = (C.c_void_p * 1)(i1.ctypes.data), (C.c_void_p * 1)(i2.ctypes.data)
+    npair = np.array([1], np.int32)
+    tr = np.full((4, 2), -1, np.int32)
+    n, mg = C.c_int(), C.c_int()
+    assert L.mcorb_host_merge_tracks(2, counts.ctypes.data, p1, p2, npair.ctypes.data, tr.ctypes.data, 4, C.byref(n), C.byref(mg)) == _lib.E_ARG
+    bad = np.array([-1, 4], np.int32)
+    i1[0] = 0
+    assert L.mcorb_host_merge_tracks(2, bad.ctypes.data, p1, p2, npair.ctypes.data, tr.ctypes.data, 4, C.byref(n), C.byref(mg)) == _lib.E_ARG
+    assert L.mcorb_host_merge_tracks(2, counts.ctypes.data, p1, p2, npair.ctypes.data, tr.ctypes.data, 4, C.byref(n), C.byref(mg)) == 0 and n.value == 1
+
+
 def test_hamming256_matches_reference_swar():
     rng = np.random.default_rng(0)
     for _ in range(100):

@@ -168,6 +168,80 @@ static void run_rate(int wps)
     CK(hipFree(d_o)); CK(hipFree(d_c));
 }
 
+
+// ---- the k-NN loop's skeleton: NCH independent accumulator chains per wave, each K = 256 (four steps, the first one taking a
+// constant register set as its C input like the kernel's row term), the A operand of a step optionally read from LDS two steps
+// ahead (ds_read_b128, 1 KiB per wave and step), no folds, no barrier: what the matrix pipe sustains in that structure ----
+template <int NCH, int LDSA>
+__global__ __launch_bounds__(256) void k_skel(float *out, unsigned long long *cyc, int iters)
+{
+    extern __shared__ uint4 lds4[];
+    for (int i = threadIdx.x; i < 2048; i += 256) lds4[i] = uint4{0x22222222u, 0x2a2a2a2au + i, 0xa2a2a2a2u, 0x22aa22aau};
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v16f Crow, acc[NCH];
+    for (int e = 0; e < 16; e++) Crow[e] = (float)(31 - e - (lane >> 5) * 4);
+    v4i Bf[NCH][4];
+    for (int u = 0; u < NCH; u++)
+        for (int s = 0; s < 4; s++) Bf[u][s] = v4i{0x2a2a2a2a + u, 0x22222222 + s, (int)0xa2a2a2a2, 0x22aa22aa};
+    float sink = 0;
+    const uint4 *S = lds4 + wave * 512 + lane;
+    v4i Af[4];
+    Af[0] = __builtin_bit_cast(v4i, S[0]); Af[1] = __builtin_bit_cast(v4i, S[64]);
+    Af[2] = Af[0]; Af[3] = Af[1];
+    const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int g = 0; g < 8; g++) {   // two tiles
+            const int s = g & 3;
+            if (LDSA) Af[(g + 2) & 3] = __builtin_bit_cast(v4i, S[((g + 2) & 7) * 64]);
+            else asm volatile("" : "+v"(Af[(g + 2) & 3][0]));
+            const v4i a = Af[g & 3];
+            const v8i A = {a[0], a[1], a[2], a[3], 0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < NCH; u++) {
+                const v8i B = {Bf[u][s][0], Bf[u][s][1], Bf[u][s][2], Bf[u][s][3], 0, 0, 0, 0};
+                acc[u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, s == 0 ? Crow : acc[u], 4, 4, 0, 0x85858585, 0, 0x85858585);
+            }
+            if (s == 3) {
+#pragma unroll
+                for (int u = 0; u < NCH; u++) asm volatile("" :: "v"(acc[u][0]), "v"(acc[u][15]));   // the tile's result is "used"
+            }
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    for (int u = 0; u < NCH; u++) sink += acc[u][3];
+    if (sink == 12345.678f) out[0] = sink;
+    if (lane == 0) {
+        unsigned long long *o = cyc + (size_t)(blockIdx.x * 4 + wave) * 2;
+        o[0] = t1 - t0;
+        o[1] = r1 - r0;
+    }
+}
+
+template <int NCH, int LDSA>
+static void run_skel(int wps)
+{
+    const int iters = 500, ncu = 256, nwg = ncu * wps;
+    const size_t lds = std::max<size_t>((size_t)(160 * 1024 / (wps + 0.5)), 2048 * 16);
+    float *d_o; unsigned long long *d_c;
+    CK(hipMalloc(&d_o, 64)); CK(hipMalloc(&d_c, (size_t)nwg * 4 * 16));
+    CK(hipFuncSetAttribute((const void *)k_skel<NCH, LDSA>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int rep = 0; rep < 2; rep++) k_skel<NCH, LDSA><<<nwg, 256, lds>>>(d_o, d_c, iters);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> c((size_t)nwg * 8);
+    CK(hipMemcpy(c.data(), d_c, c.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> per;
+    for (int w = 0; w < nwg * 4; w++) per.push_back((double)c[2 * w] / (iters * 8.0 * NCH));
+    std::sort(per.begin(), per.end());
+    printf("  skeleton chains=%d A-from-%s wps=%d: wave cycles per matrix instruction %6.1f -> per SIMD %6.1f\n", NCH, LDSA ? "LDS" : "reg", wps,
+           per[per.size() / 2], per[per.size() / 2] / wps);
+    CK(hipFree(d_o)); CK(hipFree(d_c));
+}
+
 int main()
 {
     printf("fp4_probe: v_mfma_scale_f32_32x32x64_f8f6f4 (e2m1 x e2m1) as a Hamming-distance engine\n\n1. exactness (mismatching elements of 1024 per case; 0 = exact)\n");
@@ -185,5 +259,8 @@ int main()
     run_rate<1, 8>(1);  run_rate<1, 16>(1); run_rate<1, 24>(1); run_rate<1, 32>(1);
     run_rate<1, 8>(3);  run_rate<1, 12>(3); run_rate<1, 16>(3); run_rate<1, 24>(3); run_rate<1, 32>(3);
     run_rate<0, 16>(3); run_rate<0, 32>(3);
+    printf("\n4. the k-NN loop's skeleton (K = 256 chains, first step with a constant C input)\n");
+    run_skel<1, 0>(1); run_skel<2, 0>(1); run_skel<4, 0>(1); run_skel<1, 0>(3); run_skel<2, 0>(3); run_skel<2, 0>(2); run_skel<4, 0>(2);
+    run_skel<2, 1>(1); run_skel<4, 1>(1); run_skel<2, 1>(3); run_skel<2, 1>(2); run_skel<4, 1>(2);
     return total ? 1 : 0;
 }
