@@ -37,6 +37,13 @@ extern "C" {
 #define MCORB_MAX_LEVELS 16
 #define MCORB_MAX_CAMS 16      /* IntraMatch::matchIndex is array<int,5> in the reference
                                   (MultiCameraFrame.h:44); widened here for the 8-camera rig */
+/* DistributeOctTree (ORBextractor.cpp:554-778) after the GPU bucketing: HOST = worker threads between two GPU phases (needs ~10 cores
+ * per GPU at full rate); GPU = one wave per (image, level), the whole job is one submission and the host only reads results
+ * (levels whose tree goes below the bucketing depth -- clustered corners -- fall back to the host stage for that batch).
+ * AUTO = GPU, unless the environment says MCORB_SELECT=host|gpu. */
+#define MCORB_SELECT_AUTO 0
+#define MCORB_SELECT_HOST 1
+#define MCORB_SELECT_GPU 2
 #define MCORB_ORIENT_NONE 0    /* reference behaviour: angle = 0 (ORBextractor.cpp:475) */
 #define MCORB_ORIENT_IC_ANGLE 1 /* the reference's dormant IC_Angle (ORBextractor.cpp:75-102) */
 
@@ -59,7 +66,8 @@ typedef struct mcorb_params {
     int host_threads;     /* selection workers; 0 = one per camera image, capped at hw concurrency */
     int cand_cap;         /* host-side candidate slots per image (the device list is sized for the worst case);
                              only sparse levels are copied to the host; 0 = default (max(65536, w*h/4)) */
-    int reserved[7];
+    int selection;        /* MCORB_SELECT_*: where DistributeOctTree's list discipline runs (0 = default) */
+    int reserved[6];
 } mcorb_params;
 
 void mcorb_default_params(mcorb_params *p);   /* 2000, 1.2, 8, 20, 7, none, dev 0 */
@@ -161,10 +169,16 @@ int mcorb_rig_get_candidates(mcorb_rig *r, int slot, int m, int level, uint32_t 
 
 /* timing of the last completed job of a slot, microseconds between HIP events
  * recorded on the slot's stream around the launches:
- * [0] pyramid+FAST+compaction, [1] host selection wall time, [2] blur + describe(+D2H),
+ * [0] pyramid+FAST+compaction, [1] selection: host wall time (MCORB_SELECT_HOST) or k_select + k_assemble (MCORB_SELECT_GPU), [2] blur + describe(+D2H),
  * [3] k-NN + finalize, [4] pyramid launches, [5] FAST kernel alone, [6] compaction kernel (side stream),
  * [7] k-NN kernel alone, [8] blur kernel, [9] describe kernel */
 int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[10]);
+/* MCORB_SELECT_HOST or MCORB_SELECT_GPU: what this rig runs; jobs of a slot that fell back to the host stage so far */
+int mcorb_rig_select_mode(mcorb_rig *r);
+int mcorb_rig_select_fallbacks(mcorb_rig *r, int slot);
+/* test hook for the GPU selection's sort: the permutation std::sort (libstdc++) leaves n keys in, computed by one GPU wave
+ * (perm_dev) and by std::sort itself on the host (perm_std); entries compare by key only (mcorb_sortmodel.h) */
+int mcorb_dev_sort_selftest(int device, const uint32_t *keys, int n, uint32_t *perm_dev, uint32_t *perm_std);
 
 /* multi-GPU plumbing (one process per GPU; the collective itself is the
  * caller's: bench.py's throughput path uses one RCCL all-to-all with uneven splits per round, its

@@ -302,6 +302,14 @@ class Rig:
         d["host_threads"] = int(self.L.mcorb_rig_host_threads(self.h_rig))
         return d
 
+    def select_mode(self):
+        """'gpu' (DistributeOctTree's list discipline in k_select: a job is one submission) or 'host' (worker pool between two GPU phases)"""
+        return {1: "host", 2: "gpu"}[self.L.mcorb_rig_select_mode(self.h_rig)]
+
+    def select_fallbacks(self, slot=0):
+        """jobs of the slot the host stage had to redo (a level whose tree went below the GPU bucketing depth)"""
+        return int(self.L.mcorb_rig_select_fallbacks(self.h_rig, slot))
+
     def timing(self, slot=0):
         t = (C.c_float * 10)()
         _lib.check(self.L.mcorb_rig_last_timing(self.h_rig, slot, t))

@@ -24,8 +24,8 @@ KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4
 class Params(C.Structure):
     _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
                 ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("orientation", C.c_int),
-                ("device_id", C.c_int), ("host_threads", C.c_int), ("cand_cap", C.c_int),
-                ("reserved", C.c_int * 7)]
+                ("device_id", C.c_int), ("host_threads", C.c_int), ("cand_cap", C.c_int), ("selection", C.c_int),
+                ("reserved", C.c_int * 6)]
 
 
 class Camera(C.Structure):
@@ -76,6 +76,9 @@ SIGNATURES = {
     "mcorb_rig_get_blurred": (_i, [_vp, _i, _i, _i, _vp, _i]),
     "mcorb_rig_get_candidates": (_i, [_vp, _i, _i, _i, _vp, _i, _ip]),
     "mcorb_rig_last_timing": (_i, [_vp, _i, C.POINTER(_f)]),
+    "mcorb_rig_select_mode": (_i, [_vp]),
+    "mcorb_rig_select_fallbacks": (_i, [_vp, _i]),
+    "mcorb_dev_sort_selftest": (_i, [_i, _vp, _i, _vp, _vp]),
     "mcorb_rig_match_pairs_external": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _f, _f]),
     "mcorb_rig_match_pairs_external_dev_submit": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _f, _f, _vp]),
     "mcorb_rig_get_pairlist": (_i, [_vp, _i, _i, _vp, _vp, _i, _ip]),

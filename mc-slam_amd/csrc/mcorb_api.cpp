@@ -348,7 +348,15 @@ int mcorb_rig_get_candidates(mcorb_rig *r, int slot, int m, int level, uint32_t 
     if (!s) return MCORB_E_STATE;
     const Geom &g = r->rig.geom;
     if (m < 0 || m >= s->nimg_done || level < 0 || level >= g.nlevels) { set_error("bad candidate request"); return MCORB_E_ARG; }
+    // level offsets of the image's table block: in host memory only when the job wrote them there (a small batch of the host
+    // selection path) or brought them over; the device copy is what every other job leaves
+    int lo_dev[kMaxLevels + 1];
     const int *lo = s->tbl(m) + kTblLvlOff;
+    if (!s->small_job) {
+        HIPCHK(hipSetDevice(r->rig.device));
+        HIPCHK(hipMemcpy(lo_dev, s->d_tbl + (size_t)m * s->tbl_ints_per_image + kTblLvlOff, sizeof(lo_dev), hipMemcpyDeviceToHost));
+        lo = lo_dev;
+    }
     const int n = lo[level + 1] - lo[level];
     if (n_out) *n_out = n;
     if (n > cap) { set_error("candidate buffer too small"); return MCORB_E_CAP; }
@@ -381,6 +389,33 @@ int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[10])
 }
 
 int mcorb_rig_kcap(mcorb_rig *r) { return r ? r->rig.geom.kcap : MCORB_E_ARG; }
+int mcorb_rig_select_mode(mcorb_rig *r) { return r ? (r->rig.gpu_select ? MCORB_SELECT_GPU : MCORB_SELECT_HOST) : MCORB_E_ARG; }
+int mcorb_rig_select_fallbacks(mcorb_rig *r, int slot)
+{
+    if (!r || slot < 0 || slot >= (int)r->rig.slots.size()) return MCORB_E_ARG;
+    return r->rig.slots[slot]->fallbacks;
+}
+int mcorb_dev_sort_selftest(int device, const uint32_t *keys, int n, uint32_t *perm_dev, uint32_t *perm_std)
+{
+    if (n < 0 || n > 6000 || (n && (!keys || !perm_dev || !perm_std))) { set_error("sort_selftest: bad argument"); return MCORB_E_ARG; }
+    if (n == 0) return MCORB_OK;
+    std::vector<uint64_t> a((size_t)n), b((size_t)n);
+    for (int i = 0; i < n; i++) a[i] = ((uint64_t)keys[i] << 32) | (uint32_t)i;
+    b = a;
+    std::sort(b.begin(), b.end(), [](uint64_t x, uint64_t y) { return (x >> 32) < (y >> 32); });
+    for (int i = 0; i < n; i++) perm_std[i] = (uint32_t)b[i];
+    HIPCHK(hipSetDevice(device));
+    uint64_t *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_in, (size_t)n * 8));
+    if (hipMalloc((void **)&d_out, (size_t)n * 8) != hipSuccess) { (void)hipFree(d_in); set_error("sort_selftest: out of device memory"); return MCORB_E_HIP; }
+    hipError_t e = hipMemcpy(d_in, a.data(), (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = sort_selftest(d_in, n, d_out);
+    if (e == hipSuccess) e = hipMemcpy(b.data(), d_out, (size_t)n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return MCORB_E_HIP; }
+    for (int i = 0; i < n; i++) perm_dev[i] = (uint32_t)b[i];
+    return MCORB_OK;
+}
 int mcorb_rig_host_threads(mcorb_rig *r) { return r ? r->rig.pool_threads : MCORB_E_ARG; }
 int mcorb_rig_info(mcorb_rig *r, int32_t out[8])
 {

@@ -470,6 +470,13 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
     // runtime's copy gives 4-6 % more frames/s although k_expand / k_knn2 run stretched beside it; with one slot (latency mode)
     // ours keeps k_expand at 12 us instead of 150 and the frame a few % shorter.  MCORB_COPY_KERNEL=0|1 overrides.
     copy_kernel = getenv("MCORB_COPY_KERNEL") ? atoi(getenv("MCORB_COPY_KERNEL")) != 0 : nslots == 1;
+    {   // where DistributeOctTree's list discipline runs (include/mcorb.h, MCORB_SELECT_*)
+        const char *e = getenv("MCORB_SELECT");
+        int mode = p.selection;
+        if (mode == MCORB_SELECT_AUTO && e) mode = !strcmp(e, "host") ? MCORB_SELECT_HOST : (!strcmp(e, "gpu") ? MCORB_SELECT_GPU : MCORB_SELECT_AUTO);
+        if (mode != MCORB_SELECT_AUTO && mode != MCORB_SELECT_HOST && mode != MCORB_SELECT_GPU) { set_error("mcorb_params.selection: unknown mode"); return MCORB_E_ARG; }
+        gpu_select = mode != MCORB_SELECT_HOST;
+    }
     pool = new WorkerPool(nthreads);
     pool_threads = nthreads;
     for (int i = 0; i < nthreads + nslots; i++) scratch.push_back(new SelectScratch);   // workers, then one per slot's submitting thread
@@ -528,6 +535,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
             const size_t o_pairs = align_up(o_setmap + M * sizeof(int), 64);
             const size_t o_sel = align_up(o_pairs + (size_t)npairs_max * sizeof(int2), 64);
             s->ctrl_pairs_end = o_sel;
+            s->ctrl_nsel_off = o_nsel;
             s->ctrl_bytes = o_sel + M * geom.kcap * sizeof(uint32_t);
             TRY(host_alloc(&s->h_ctrl, s->ctrl_bytes));
             TRY(dev_alloc(&s->d_ctrl, s->ctrl_bytes));
@@ -537,6 +545,17 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
             s->h_setmap = (int *)(s->h_ctrl + o_setmap);  s->d_setmap = (int *)(s->d_ctrl + o_setmap);
             s->h_pairs = (int2 *)(s->h_ctrl + o_pairs);   s->d_pairs = (int2 *)(s->d_ctrl + o_pairs);
             s->h_sel = (uint32_t *)(s->h_ctrl + o_sel);   s->d_sel = (uint32_t *)(s->d_ctrl + o_sel);
+        }
+        if (gpu_select) {
+            TRY(dev_alloc(&s->d_selval, M * geom.nlevels * (size_t)select_cap(geom)));
+            TRY(dev_alloc(&s->d_selcnt, M * geom.nlevels));
+            s->res_mono_off = 16 * sizeof(int);
+            s->res_resp_off = align_up(s->res_mono_off + M * sizeof(int), 64);
+            s->res_bytes = align_up(s->res_resp_off + M * geom.kcap, 64);
+            TRY(dev_alloc(&s->d_res, s->res_bytes));
+            TRY(host_alloc(&s->h_res, s->res_bytes));
+            HIPCHK(hipMemset(s->d_res, 0, s->res_bytes));
+            HIPCHK(hipEventCreateWithFlags(&s->ev_s, hipEventDefault));
         }
         TRY(host_alloc(&s->h_stage, M * (size_t)W * H));
         TRY(host_alloc(&s->h_desc, M * geom.kcap * 32));
@@ -579,6 +598,8 @@ Rig::~Rig()
         (void)hipFree(s->d_knn); (void)hipHostFree(s->h_mlist); (void)hipHostFree(s->h_mcount); (void)hipHostFree(s->h_ctrl); (void)hipFree(s->d_ctrl);
         (void)hipHostFree(s->h_stage);
         (void)hipHostFree(s->h_desc); (void)hipHostFree(s->h_angles);
+        (void)hipFree(s->d_selval); (void)hipFree(s->d_selcnt); (void)hipFree(s->d_res); (void)hipHostFree(s->h_res);
+        if (s->ev_s) (void)hipEventDestroy(s->ev_s);
         for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
         if (s->ev_x) (void)hipEventDestroy(s->ev_x);
         if (s->ev_c) (void)hipEventDestroy(s->ev_c);
@@ -728,14 +749,20 @@ int Rig::execute(Slot &s, const Job &j)
     int st = MCORB_OK;
     switch (j.kind) {
     case Job::EXTRACT:
+        if (gpu_select) { st = run_gpu_selected(s, j, false); break; }
         st = run_extract_phaseA(s, j);
         if (st == MCORB_OK) st = run_select_and_describe(s, j, false);
         break;
     case Job::PROCESS:
         LatProf::mark(0);
-        st = run_extract_phaseA(s, j);
-        LatProf::mark(1);
-        if (st == MCORB_OK) st = run_select_and_describe(s, j, true);
+        if (gpu_select) {
+            st = run_gpu_selected(s, j, true);
+            LatProf::mark(1); LatProf::mark(2); LatProf::mark(3); LatProf::mark(4); LatProf::mark(5);
+        } else {
+            st = run_extract_phaseA(s, j);
+            LatProf::mark(1);
+            if (st == MCORB_OK) st = run_select_and_describe(s, j, true);
+        }
         LatProf::mark(6);
         if (st == MCORB_OK) st = finish_match(s, j);
         LatProf::mark(7);
@@ -1021,6 +1048,111 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
     (void)hipEventElapsedTime(&t, s.ev[0], s.ev[1]); s.timing[4] = t * 1000.f;   // pyramid launches
     (void)hipEventElapsedTime(&t, s.ev[1], s.ev[2]); s.timing[5] = t * 1000.f;   // k_fast_cells
     (void)hipEventElapsedTime(&t, s.ev[2], s.ev_c); s.timing[6] = t * 1000.f;   // k_compact (the table DMA behind it is not included)
+    return MCORB_OK;
+}
+
+// MCORB_SELECT_GPU: the whole job -- pyramid, FAST, compaction, selection, assembly, descriptors, matching -- is enqueued in one go;
+// the host comes back when the results have landed (descriptors, the control block's sel / nsel, responses, monoIndex, flags) and
+// only builds its keypoint records from them.  A batch with a level whose tree goes below the bucketing depth (flag) is redone
+// through the host stage: run_select_and_describe on the tables, exactly the MCORB_SELECT_HOST path.
+int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
+{
+    if (j.nimg < 1 || j.nimg > max_images) { set_error("extract: bad image count"); return MCORB_E_ARG; }
+    const int nimg = j.nimg;
+    s.invalidate_bow();
+    s.small_job = false;
+    s.h_overflow[0] = 0;
+    s.nimg_done = nimg;
+    if (then_match) {
+        // pair list / set map first: k_assemble overwrites the control block's nsel and sel afterwards, in stream order
+        TRY(prepare_match(s, j));
+        HIPCHK(hipMemcpyAsync(s.d_ctrl, s.h_ctrl, s.ctrl_pairs_end, hipMemcpyHostToDevice, s.st));
+    }
+    int *d_flags = reinterpret_cast<int *>(s.d_res);
+    HIPCHK(hipMemsetAsync(d_flags, 0, 16 * sizeof(int), s.st));
+    HIPCHK(hipEventRecord(s.ev[0], s.st));
+    launch_pyramid(s.st, s.d_pyr, geom, d_taps, resize_win, nimg);
+    HIPCHK(hipEventRecord(s.ev[1], s.st));
+    launch_fast(s.st, s.d_pyr, geom, params.ini_th_fast, params.min_th_fast, d_fasttab + fast_cell_off, s.d_cellkp, s.d_cellcnt, nimg);
+    HIPCHK(hipEventRecord(s.ev[2], s.st));
+    launch_compact(s.st, s.d_cellkp, s.d_cellcnt, geom, d_lut, s.d_sorted, s.h_cand, s.d_tbl, s.h_overflow, nimg);
+    HIPCHK(hipEventRecord(s.ev_c, s.st));
+    HIPCHK(launch_select(s.st, s.d_tbl, geom, s.d_selval, s.d_selcnt, d_flags, nimg));
+    launch_assemble(s.st, s.d_selval, s.d_selcnt, geom, tab.scale, j.lap0, j.lap1, s.d_sel, s.d_res + s.res_resp_off, s.d_nsel,
+                    reinterpret_cast<int *>(s.d_res + s.res_mono_off), d_flags, nimg);
+    HIPCHK(hipEventRecord(s.ev_s, s.st));
+    HIPCHK(hipEventRecord(s.ev[3], s.st));
+    s.blur_valid = blur_planes;
+    if (blur_planes) launch_blur(s.st, s.d_pyr, s.d_blur, geom, nimg);
+    HIPCHK(hipEventRecord(s.ev[4], s.st));
+    HIPCHK(hipEventRecord(s.ev[5], s.st));
+    launch_describe(s.st, s.d_pyr, blur_planes ? s.d_blur : nullptr, geom, s.d_sel, s.d_nsel, params.orientation, s.d_desc, s.d_angles, nimg);
+    HIPCHK(hipEventRecord(s.ev[6], s.st));
+    // results to the host on the side stream while the matcher runs: descriptors, the control block from nsel on (nsel, the set
+    // map and pair list as uploaded, sel), responses + monoIndex + flags
+    HIPCHK(hipStreamWaitEvent(s.st_dma, s.ev[6], 0));
+    if (!copy_kernel) HIPCHK(hipMemcpyAsync(s.h_desc, s.d_desc, (size_t)nimg * geom.kcap * 32, hipMemcpyDeviceToHost, s.st_dma));
+    else launch_copy_to_host(s.st_dma, s.d_desc, s.h_desc, (size_t)nimg * geom.kcap * 32);
+    HIPCHK(hipMemcpyAsync(s.h_ctrl + s.ctrl_nsel_off, s.d_ctrl + s.ctrl_nsel_off, s.ctrl_pairs_end - s.ctrl_nsel_off + (size_t)nimg * geom.kcap * sizeof(uint32_t),
+                          hipMemcpyDeviceToHost, s.st_dma));
+    HIPCHK(hipMemcpyAsync(s.h_res, s.d_res, s.res_resp_off + (size_t)nimg * geom.kcap, hipMemcpyDeviceToHost, s.st_dma));
+    if (params.orientation)
+        HIPCHK(hipMemcpyAsync(s.h_angles, s.d_angles, (size_t)nimg * geom.kcap * sizeof(float), hipMemcpyDeviceToHost, s.st_dma));
+    if (then_match) TRY(enqueue_match(s, j, true));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(s.ev[10], s.st));
+    HIPCHK(hipEventRecord(s.ev[11], s.st_dma));
+    HIPCHK(wait_event(s.ev[10]));
+    HIPCHK(wait_event(s.ev[11]));
+    if (s.h_overflow[0]) { set_error("candidate list of a sparse level does not fit the host buffer (raise mcorb_params.cand_cap)"); return MCORB_E_OVERFLOW; }
+    const int flags = reinterpret_cast<const int *>(s.h_res)[0];
+    if (flags) {
+        // the host stage on the same tables (bit 0: a tree below the bucketing depth; bit 1: more than kcap keypoints -- the host
+        // stage reports that error itself)
+        s.fallbacks++;
+        HIPCHK(hipMemcpyAsync(s.h_tbl, s.d_tbl, (size_t)nimg * s.tbl_ints_per_image * sizeof(int), hipMemcpyDeviceToHost, s.st_copy));
+        HIPCHK(hipEventRecord(s.ev[3], s.st_copy));
+        return run_select_and_describe(s, j, then_match);
+    }
+    // keypoint records (ORBextractor.cpp:1103-1170's fields) from what k_assemble left: one pool task per image
+    const int *mono = reinterpret_cast<const int *>(s.h_res + s.res_mono_off);
+    const uint8_t *resp = s.h_res + s.res_resp_off;
+    pool->parallel_for(nimg, [&](int m, int) {
+        const int n = s.h_nsel[m];
+        std::vector<mcorb_keypoint> &K = s.kps[m];
+        K.resize((size_t)n);
+        const uint32_t *sel = s.h_sel + (size_t)m * geom.kcap;
+        const uint8_t *rs = resp + (size_t)m * geom.kcap;
+        const float *ang = params.orientation ? s.h_angles + (size_t)m * geom.kcap : nullptr;
+        for (int k = 0; k < n; k++) {
+            const uint32_t v = sel[k];
+            const int l = (int)(v >> 28), yl = (int)((v >> 14) & 0x3fffu), xl = (int)(v & 0x3fffu);
+            mcorb_keypoint kp;
+            kp.x = (float)xl; kp.y = (float)yl;
+            kp.size = (float)tab.scaled_patch[l];
+            kp.angle = ang ? ang[k] : 0.f;
+            kp.response = (float)rs[k];
+            kp.octave = l;
+            kp.class_id = -1;
+            if (l != 0) { kp.x *= tab.scale[l]; kp.y *= tab.scale[l]; }
+            K[k] = kp;
+        }
+        s.mono[m] = mono[m];
+    }, pool_threads + s.index);
+    if (then_match && !j.ext_desc)
+        for (size_t i = 0; i < s.match_counts.size(); i++) s.match_counts[i] = s.h_nsel[s.match_sets[i]];
+    float a = 0, b = 0, c = 0, t = 0;
+    (void)hipEventElapsedTime(&a, s.ev[0], s.ev[2]);
+    (void)hipEventElapsedTime(&b, s.ev[3], s.ev[4]);
+    (void)hipEventElapsedTime(&c, s.ev[5], s.ev[6]);
+    s.timing[0] = a * 1000.f;
+    s.timing[2] = (b + c) * 1000.f;
+    s.timing[8] = b * 1000.f;
+    s.timing[9] = c * 1000.f;
+    (void)hipEventElapsedTime(&t, s.ev[0], s.ev[1]); s.timing[4] = t * 1000.f;
+    (void)hipEventElapsedTime(&t, s.ev[1], s.ev[2]); s.timing[5] = t * 1000.f;
+    (void)hipEventElapsedTime(&t, s.ev[2], s.ev_c); s.timing[6] = t * 1000.f;
+    (void)hipEventElapsedTime(&t, s.ev_c, s.ev_s); s.timing[1] = t * 1000.f;   // k_select + k_assemble
     return MCORB_OK;
 }
 

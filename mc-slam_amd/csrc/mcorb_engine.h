@@ -154,6 +154,14 @@ struct Slot {
     int *d_extcounts = nullptr, *d_nsel = nullptr, *d_setmap = nullptr;
     int2 *d_pairs = nullptr;
     uint32_t *d_sel = nullptr;
+    // GPU selection (MCORB_SELECT_GPU): k_select's per-(image, level) lists, and the result block k_assemble fills for the host
+    // ([16 ints of flags][mono M ints][responses M x kcap bytes]; sel / nsel are written into the control block)
+    uint32_t *d_selval = nullptr;
+    int *d_selcnt = nullptr;
+    uint8_t *d_res = nullptr, *h_res = nullptr;
+    size_t res_bytes = 0, res_mono_off = 0, res_resp_off = 0, ctrl_nsel_off = 0;
+    int fallbacks = 0;         // jobs of this slot the host stage had to redo (a tree below the bucketing depth)
+    hipEvent_t ev_s = nullptr; // k_select + k_assemble finished
     // host, pinned
     uint8_t *h_stage = nullptr, *h_desc = nullptr;
     float *h_angles = nullptr;
@@ -227,6 +235,7 @@ public:
     std::vector<Slot *> slots;
     WorkerPool *pool = nullptr;
     int pool_threads = 0;
+    bool gpu_select = false;   // DistributeOctTree's list discipline runs in k_select (MCORB_SELECT_GPU); else on the worker pool
     int wait_mode = 0;         // how a thread waits for a HIP event: 0 spin (hipEventSynchronize), 1 interrupt-driven, 2 poll + short sleeps
     hipError_t wait_event(hipEvent_t ev) const;
     std::vector<SelectScratch *> scratch;   // one per worker
@@ -241,6 +250,7 @@ private:
     int execute(Slot &s, const Job &j);
     int run_extract_phaseA(Slot &s, const Job &j);
     int run_select_and_describe(Slot &s, const Job &j, bool then_match);
+    int run_gpu_selected(Slot &s, const Job &j, bool then_match);   // the whole job as one submission (gpu_select)
     int prepare_match(Slot &s, const Job &j);
     int enqueue_match(Slot &s, const Job &j, bool ctrl_on_device);
     int finish_match(Slot &s, const Job &j);

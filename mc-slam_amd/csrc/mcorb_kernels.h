@@ -65,6 +65,17 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
                  int kcap, void *expanded, int *lcounts, uint2 *part, float dist_thresh, float ratio, KnnRow *out, uint32_t *mlist,
                  int *mcount, hipEvent_t ev_exp, hipEvent_t ev_mid);   // events (optional): after k_expand, after k_knn2
 
+// DistributeOctTree's list discipline + operator()'s assembly on the GPU (mcorb_select_gpu.hip).  tbl: k_compact's device table
+// blocks; sel_val / sel_cnt: select_cap(g) retained candidates and their count per (image, level), -1 = the level needs the host
+// stage (fallback |= 1); sel / nsel: what the descriptor kernel and the matcher read; resp / mono: FAST responses and monoIndex
+// for the host's keypoint records; fallback bit 1 = more than kcap keypoints.
+int select_cap(const Geom &g);
+hipError_t launch_select(hipStream_t st, const int *tbl, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg);
+void launch_assemble(hipStream_t st, const uint32_t *sel_val, const int *sel_cnt, const Geom &g, const float *scale, int lap0, int lap1,
+                     uint32_t *sel, uint8_t *resp, int *nsel, int *mono, int *fallback, int nimg);
+// test hook: std::sort's permutation of n 64-bit entries (upper halves compared) by one wave (wave_std_sort)
+hipError_t sort_selftest(const uint64_t *in_dev, int n, uint64_t *out_dev);
+
 // device -> host-mapped pinned memory with a small grid (instead of the runtime's blit kernel); sizes rounded up to 16 bytes
 void launch_copy_to_host(hipStream_t st, const void *src_dev, void *dst_host_mapped, size_t bytes);
 

@@ -1,0 +1,553 @@
+// mcorb_select_gpu.hip -- DistributeOctTree's list discipline on the GPU (ORBextractor.cpp:554-778), one wave per (image, level).
+//
+// k_compact has already counting-sorted a level's FAST candidates by quad-tree path code and found every bucket's winner
+// (mcorb_kernels.hip); what the host stage (mcorb_select.cpp) did with those tables -- the std::list push_front / erase sequence,
+// the std::sort of (key count, UL.x) and the largest-first divisions until N nodes exist -- happens here, so that a batch is ONE
+// submission: pyramid, FAST, compaction, selection, assembly, descriptors, matching, with no host round trip in the middle.
+//
+// * A full pass (:615-678) divides every node with more than one key; children are pushed to the FRONT in n1..n4 order, nodes
+//   with one key stay where they are.  The new list is therefore: the children of the dividable nodes in REVERSE node order, each
+//   node's non-empty children in n4, n3, n2, n1 order, then the single-key nodes in their old order -- positions are prefix sums.
+// * The careful phase (:688-752) sorts the dividable nodes by (key count, UL.x) with std::sort and divides from the back until N
+//   nodes exist.  std::sort is restated in mcorb_sortmodel.h (closed-form partitions, block-wise stable finish, heap fallback --
+//   pinned against libstdc++ on the CPU); how many nodes get divided is a prefix sum over the sorted order, the new list again
+//   a set of positions.
+// * The final pick (:757-775) is the best of the node's bucket winners.
+// A node at the bucketing depth that has to be divided again needs the candidates themselves (clustered corners): the kernel
+// raises the image's fallback flag and the engine runs the host stage for that batch (mcorb_engine.cpp), exactly as before.
+//
+// k_assemble then does ORBextractor::operator()'s assembly (:1103-1170): level order, coordinate scaling, the lapping partition
+// (mono keypoints from the front, stereo ones from the back).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#include "mcorb_common.h"
+#include "mcorb_kernels.h"
+#include "mcorb_sortmodel.h"
+
+namespace mcorb {
+
+namespace {
+
+__device__ __forceinline__ int sel_lane() { return threadIdx.x & 63; }
+__device__ __forceinline__ int sel_rank(unsigned long long mask, int acc = 0)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, (uint32_t)acc));
+}
+__device__ __forceinline__ void sel_sync()   // LDS written by some lanes of this wave, read by others
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ int sel_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ int sel_scan(int v)   // inclusive prefix sum over the wave
+{
+    const int lane = sel_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ int sel_total(int incl) { return __shfl(incl, 63); }
+
+// a tree node: x = path code | depth << 24, y = UL.x | UR.x << 16 (level coordinates relative to minX; the y extent is not needed:
+// only UL.x enters compareNodes, and the key sets come from the bucket table)
+__device__ __forceinline__ uint32_t node_code(uint2 n) { return n.x & 0xffffffu; }
+__device__ __forceinline__ int node_depth(uint2 n) { return (int)(n.x >> 24); }
+__device__ __forceinline__ int node_count(const int *bst, uint2 n, int D)
+{
+    const int sh = 2 * (D - node_depth(n));
+    return bst[(node_code(n) + 1) << sh] - bst[node_code(n) << sh];
+}
+// DivideNode (:479-535) on bucket ranges: key counts of n1..n4
+__device__ __forceinline__ void node_kids(const int *bst, uint2 n, int D, int cnt[4])
+{
+    const int sh = 2 * (D - node_depth(n) - 1);
+    const int base = (int)((node_code(n) << 2) << sh);
+    const int e0 = bst[base], e1 = bst[base + (1 << sh)], e2 = bst[base + (2 << sh)], e3 = bst[base + (3 << sh)], e4 = bst[base + (4 << sh)];
+    cnt[0] = e1 - e0; cnt[1] = e2 - e1; cnt[2] = e3 - e2; cnt[3] = e4 - e3;
+}
+__device__ __forceinline__ uint2 node_child(uint2 n, int q)
+{
+    const int x0 = (int)(n.y & 0xffffu), x1 = (int)(n.y >> 16);
+    const int sx = x0 + ((x1 - x0 + 1) >> 1);   // UL.x + ceil((UR.x - UL.x) / 2)
+    const int cx0 = (q & 1) ? sx : x0, cx1 = (q & 1) ? x1 : sx;
+    return uint2{((node_code(n) << 2) | (uint32_t)q) | ((uint32_t)(node_depth(n) + 1) << 24), (uint32_t)cx0 | ((uint32_t)cx1 << 16)};
+}
+// per-node summary of a division: non-empty children (bits 0-3), children with more than one key (bits 4-7), 0x100 = dividable
+__device__ __forceinline__ uint32_t kids_info(const int cnt[4])
+{
+    uint32_t m = 0x100u;
+#pragma unroll
+    for (int q = 0; q < 4; q++) m |= (cnt[q] > 0 ? 1u << q : 0u) | (cnt[q] > 1 ? 16u << q : 0u);
+    return m;
+}
+
+struct SelLds {
+    int *bst;                 // bucket starts of this level (B + 1)
+    uint2 *list[2];           // node lists, ping-pong
+    uint64_t *exp[2];         // (key count << 12 | UL.x) << 32 | list position of the nodes that can still be divided
+    uint16_t *ta, *tb;        // scratch: partition positions (sort) / per-node and per-entry division summaries (passes)
+    uint32_t *blk;            // sort: block of every position (first | last << 16)
+    int *stk;                 // sort: range stack
+};
+constexpr int kSelStack = 3 * 48;
+__host__ __device__ inline size_t sel_lds_bytes(int B, int cap) { return (size_t)(B + 1 + 3) / 4 * 16 + (size_t)cap * (2 * 8 + 2 * 8 + 2 * 2 + 4) + kSelStack * 4; }
+
+// std::sort(a, a + n) on the upper halves, libstdc++'s permutation (mcorb_sortmodel.h); the result is in `out`
+__device__ void wave_std_sort(uint64_t *a, int n, uint64_t *out, SelLds &S)
+{
+    const int lane = sel_lane();
+    uint16_t *lp = S.ta, *rp = S.tb;
+    if (n <= 0) return;
+    int sp = 0;
+    if (lane == 0) { S.stk[0] = 0; S.stk[1] = n; S.stk[2] = 2 * sm_lg(n); }
+    sp = 1;
+    sel_sync();
+    while (sp > 0) {
+        sp--;
+        int f = sel_uni(S.stk[3 * sp]), l = sel_uni(S.stk[3 * sp + 1]), dl = sel_uni(S.stk[3 * sp + 2]);
+        while (l - f > 16) {
+            if (dl == 0) {   // depth budget used up: heap sort, one lane (rare: median-of-three killers)
+                if (lane == 0) sm_heap_sort(a, f, l);
+                sel_sync();
+                break;
+            }
+            dl--;
+            const int mid = f + (l - f) / 2;
+            const uint32_t ka = sm_key(a[f + 1]), kb = sm_key(a[mid]), kc = sm_key(a[l - 1]);
+            const int mi = sm_median3(ka, kb, kc, f + 1, mid, l - 1);
+            if (lane == 0) { const uint64_t t = a[f]; a[f] = a[mi]; a[mi] = t; }
+            sel_sync();
+            const uint32_t p = sm_key(a[f]);
+            // L: positions of (f, l) with key >= p, ascending; R: positions with key <= p, descending
+            int nL = 0, nR = 0;
+            for (int c0 = f + 1; c0 < l; c0 += 64) {
+                const int i = c0 + lane;
+                const bool isL = i < l && !(sm_key(a[min(i, l - 1)]) < p);
+                const unsigned long long b = __ballot(isL);
+                if (isL) lp[sel_rank(b, nL)] = (uint16_t)i;
+                nL += __popcll(b);
+            }
+            for (int c0 = 0; c0 < l - f - 1; c0 += 64) {
+                const int i = l - 1 - (c0 + lane);
+                const bool isR = i > f && !(p < sm_key(a[max(i, f + 1)]));
+                const unsigned long long b = __ballot(isR);
+                if (isR) rp[sel_rank(b, nR)] = (uint16_t)i;
+                nR += __popcll(b);
+            }
+            sel_sync();
+            const int m = min(nL, nR);
+            int s = 0;
+            for (int c0 = 0; c0 < m; c0 += 64) {   // the swapped pairs are a prefix: L ascends, R descends
+                const int j = c0 + lane;
+                const bool ok = j < m && lp[min(j, m - 1)] < rp[min(j, m - 1)];
+                const unsigned long long b = __ballot(ok);
+                s += __popcll(b);
+                if (b != ~0ull) break;
+            }
+            const int nextL = s < nL ? (int)lp[s] : (1 << 30), lastR = s > 0 ? (int)rp[s - 1] : (1 << 30);
+            const int cut = min(nextL, lastR);
+            for (int c0 = 0; c0 < s; c0 += 64) {
+                const int j = c0 + lane;
+                if (j < s) {
+                    const int x = lp[j], y = rp[j];
+                    const uint64_t ex = a[x], ey = a[y];
+                    a[x] = ey; a[y] = ex;
+                }
+            }
+            if (lane == 0) { S.stk[3 * sp] = cut; S.stk[3 * sp + 1] = l; S.stk[3 * sp + 2] = dl; }
+            sp++;
+            l = cut;
+            sel_sync();
+        }
+        for (int t = lane; t < l - f; t += 64) S.blk[f + t] = (uint32_t)f | ((uint32_t)l << 16);
+    }
+    sel_sync();
+    // __final_insertion_sort = stable rank inside each block
+    for (int i = lane; i < n; i += 64) {
+        const uint32_t b = S.blk[i];
+        const int bf = (int)(b & 0xffffu), bl = (int)(b >> 16);
+        const uint64_t e = a[i];
+        const uint32_t ki = sm_key(e);
+        int r = 0;
+        for (int j = bf; j < bl; j++) {
+            const uint32_t kj = sm_key(a[j]);
+            r += (kj < ki || (kj == ki && j < i)) ? 1 : 0;
+        }
+        out[bf + r] = e;
+    }
+    sel_sync();
+}
+
+// one full pass over the list (:615-678); returns the new length, m = nodes that can be divided again (nToExpand)
+__device__ int full_pass(const SelLds &S, const uint2 *in, int n, uint2 *out, uint64_t *exp, int D, int cap, int &m, int &fb)
+{
+    const int lane = sel_lane();
+    const int *bst = S.bst;
+    uint16_t *info = S.ta;
+    int H = 0, bad = 0, singles = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int i = c0 + lane;
+        int nc = 0;
+        uint32_t inf = 0x100u;
+        if (i < n) {
+            const uint2 nd = in[i];
+            inf = 0;
+            if (node_count(bst, nd, D) > 1) {
+                if (node_depth(nd) >= D) bad = 1;   // would have to split a bucket: needs the candidates themselves
+                else {
+                    int cnt[4];
+                    node_kids(bst, nd, D, cnt);
+                    inf = kids_info(cnt);
+                    nc = __popc(inf & 15u);
+                }
+            }
+            info[i] = (uint16_t)inf;
+        }
+        H += sel_total(sel_scan(nc));
+        singles += __popcll(__ballot(!(inf & 0x100u)));
+    }
+    if (__ballot(bad != 0) != 0ull || H + singles > cap) { fb = 1; m = 0; return n; }
+    sel_sync();
+    int crun = 0, erun = 0, trun = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int i = c0 + lane;
+        const uint32_t inf = i < n ? info[i] : 0u;
+        const uint32_t mask = inf & 15u, emask = (inf >> 4) & 15u;
+        const int nc = __popc(mask), ne = __popc(emask);
+        const int cin = sel_scan(nc), ein = sel_scan(ne);
+        const bool single = i < n && !(inf & 0x100u);
+        const unsigned long long bs = __ballot(single);
+        if (inf & 0x100u) {
+            const uint2 nd = in[i];
+            int cnt[4];
+            node_kids(bst, nd, D, cnt);
+            const int cincl = crun + cin, eexcl = erun + ein - ne;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (!((mask >> q) & 1u)) continue;
+                const uint2 ch = node_child(nd, q);
+                const int pos = H - cincl + __popc(mask >> (q + 1));   // children pushed later (q' > q) sit further to the front
+                out[pos] = ch;
+                if ((emask >> q) & 1u)
+                    exp[eexcl + __popc(emask & ((1u << q) - 1u))] = ((uint64_t)(((uint32_t)cnt[q] << 12) | (ch.y & 0xffffu)) << 32) | (uint32_t)pos;
+            }
+        } else if (single) {
+            out[H + sel_rank(bs, trun)] = in[i];
+        }
+        crun += sel_total(cin);
+        erun += sel_total(ein);
+        trun += __popcll(bs);
+    }
+    sel_sync();
+    m = erun;
+    return H + trun;
+}
+
+// one round of the careful phase (:688-752): `srt` = the dividable nodes sorted by std::sort; divides from the back until N nodes
+__device__ int careful_round(const SelLds &S, const uint2 *in, int n, uint2 *out, const uint64_t *srt, int m, uint64_t *exp, int N, int D, int cap,
+                             int &mOut, int &fb)
+{
+    const int lane = sel_lane();
+    const int *bst = S.bst;
+    uint16_t *divided = S.ta, *einfo = S.tb;   // per old list position: divided in this round; per entry (division order): summary
+    for (int i = lane; i < n; i += 64) divided[i] = 0;
+    // division order t = 0 .. m-1 is the sorted order from the back; k = how many divisions until the list holds N nodes
+    int k = -1, srun = 0, bad = 0;
+    for (int t0 = 0; t0 < m && k < 0; t0 += 64) {
+        const int t = t0 + lane;
+        int inc = 0;
+        if (t < m) {
+            const uint2 nd = in[(uint32_t)srt[m - 1 - t]];
+            uint32_t inf = 0x100u;
+            if (node_depth(nd) >= D) bad = 1;
+            else {
+                int cnt[4];
+                node_kids(bst, nd, D, cnt);
+                inf = kids_info(cnt);
+            }
+            einfo[t] = (uint16_t)inf;
+            inc = __popc(inf & 15u) - 1;
+        }
+        const int sin = sel_scan(inc);
+        const unsigned long long reach = __ballot(t < m && n + srun + sin >= N);
+        if (reach) k = t0 + (int)__builtin_ctzll(reach) + 1;
+        srun += sel_total(sin);
+    }
+    if (k < 0) k = m;
+    sel_sync();
+    // (a node at the bucketing depth among the ones that really get divided: the host has to do this level)
+    int Hc = 0;
+    for (int t0 = 0; t0 < k; t0 += 64) {
+        const int t = t0 + lane;
+        const uint32_t inf = t < k ? einfo[t] : 0u;
+        Hc += sel_total(sel_scan(__popc(inf & 15u)));
+    }
+    {
+        int badk = 0;
+        for (int t0 = 0; t0 < k; t0 += 64) {
+            const int t = t0 + lane;
+            if (t < k && node_depth(in[(uint32_t)srt[m - 1 - t]]) >= D) badk = 1;
+        }
+        (void)bad;
+        if (__ballot(badk != 0) != 0ull || Hc + n - k > cap) { fb = 1; mOut = 0; return n; }
+    }
+    int crun = 0, erun = 0;
+    for (int t0 = 0; t0 < k; t0 += 64) {
+        const int t = t0 + lane;
+        const uint32_t inf = t < k ? einfo[t] : 0u;
+        const uint32_t mask = inf & 15u, emask = (inf >> 4) & 15u;
+        const int nc = __popc(mask), ne = __popc(emask);
+        const int cin = sel_scan(nc), ein = sel_scan(ne);
+        if (t < k) {
+            const uint32_t pos0 = (uint32_t)srt[m - 1 - t];
+            const uint2 nd = in[pos0];
+            divided[pos0] = 1;
+            int cnt[4];
+            node_kids(bst, nd, D, cnt);
+            const int cincl = crun + cin, eexcl = erun + ein - ne;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (!((mask >> q) & 1u)) continue;
+                const uint2 ch = node_child(nd, q);
+                const int pos = Hc - cincl + __popc(mask >> (q + 1));
+                out[pos] = ch;
+                if ((emask >> q) & 1u)
+                    exp[eexcl + __popc(emask & ((1u << q) - 1u))] = ((uint64_t)(((uint32_t)cnt[q] << 12) | (ch.y & 0xffffu)) << 32) | (uint32_t)pos;
+            }
+        }
+        crun += sel_total(cin);
+        erun += sel_total(ein);
+    }
+    sel_sync();
+    int trun = 0;
+    for (int c0 = 0; c0 < n; c0 += 64) {   // the nodes that were not divided keep their order behind the new children
+        const int i = c0 + lane;
+        const bool keep = i < n && divided[i] == 0;
+        const unsigned long long b = __ballot(keep);
+        if (keep) out[Hc + sel_rank(b, trun)] = in[i];
+        trun += __popcll(b);
+    }
+    sel_sync();
+    mOut = erun;
+    return Hc + trun;
+}
+
+}  // namespace
+
+// grid (images, levels), 64 threads.  out_val[(img * nlevels + level) * selcap + i]: the retained candidates (packed y | x | response)
+// in DistributeOctTree's result order; out_cnt[img * nlevels + level]: how many, or -1 = this level needs the host stage.
+__global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom g, uint32_t *__restrict__ out_val, int *__restrict__ out_cnt,
+                                               int selcap, int ldsB, int ldsCap, int *__restrict__ fallback)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sel_sh[];
+    const int lane = sel_lane();
+    const int img = blockIdx.x, level = blockIdx.y;
+    const LevelGeom &L = g.lv[level];
+    const int N = L.quota, D = L.depth, B = L.nBuckets, cap = ldsCap;
+    const int *tb = tbl + (size_t)img * tbl_ints(g.bucketTotal);
+    const int ncand = tb[kTblLvlOff + level + 1] - tb[kTblLvlOff + level];
+    int *ocnt = out_cnt + (size_t)img * g.nlevels + level;
+    uint32_t *oval = out_val + ((size_t)img * g.nlevels + level) * selcap;
+    if (ncand <= 0) {
+        if (lane == 0) *ocnt = 0;
+        return;
+    }
+    SelLds S;
+    {
+        uint8_t *p = sel_sh;
+        S.bst = reinterpret_cast<int *>(p); p += (size_t)(ldsB + 1 + 3) / 4 * 16;
+        S.list[0] = reinterpret_cast<uint2 *>(p); p += (size_t)cap * 8;
+        S.list[1] = reinterpret_cast<uint2 *>(p); p += (size_t)cap * 8;
+        S.exp[0] = reinterpret_cast<uint64_t *>(p); p += (size_t)cap * 8;
+        S.exp[1] = reinterpret_cast<uint64_t *>(p); p += (size_t)cap * 8;
+        S.blk = reinterpret_cast<uint32_t *>(p); p += (size_t)cap * 4;
+        S.ta = reinterpret_cast<uint16_t *>(p); p += (size_t)cap * 2;
+        S.tb = reinterpret_cast<uint16_t *>(p); p += (size_t)cap * 2;
+        S.stk = reinterpret_cast<int *>(p);
+    }
+    const int *bsrc = tb + kTblHead + L.bucket0;
+    for (int b = lane; b <= B; b += 64) S.bst[b] = bsrc[b];
+    sel_sync();
+    // root nodes (:567-600): empty ones are erased
+    int n, m = 0, fb = 0, cur = 0;
+    {
+        const int i = lane;
+        bool keep = false;
+        uint2 nd{0, 0};
+        if (i < L.nIni) {
+            nd.x = (uint32_t)i;
+            nd.y = (uint32_t)(int)__fmul_rn(L.hX, (float)i) | ((uint32_t)(int)__fmul_rn(L.hX, (float)(i + 1)) << 16);
+            keep = node_count(S.bst, nd, D) > 0;
+        }
+        const unsigned long long b = __ballot(keep);
+        if (keep) S.list[0][sel_rank(b)] = nd;
+        n = __popcll(b);
+    }
+    sel_sync();
+    if (L.nIni > 64 || L.nIni < 1 || N + 8 > cap) fb = 1;
+    bool finish = fb != 0;
+    while (!finish) {
+        const int prev = n;
+        n = full_pass(S, S.list[cur], n, S.list[cur ^ 1], S.exp[0], D, cap, m, fb);
+        if (fb) break;
+        cur ^= 1;
+        if (n >= N || n == prev) break;
+        if (n + 3 * m > N) {
+            int ecur = 0;
+            while (true) {
+                const int prev2 = n;
+                wave_std_sort(S.exp[ecur], m, S.exp[ecur ^ 1], S);
+                int m2 = 0;
+                n = careful_round(S, S.list[cur], n, S.list[cur ^ 1], S.exp[ecur ^ 1], m, S.exp[ecur], N, D, cap, m2, fb);
+                if (fb) break;
+                cur ^= 1;
+                m = m2;
+                if (n >= N || n == prev2) break;
+            }
+            break;
+        }
+    }
+    if (fb || n > selcap) {
+        if (lane == 0) { *ocnt = -1; atomicOr(fallback, 1); }
+        return;
+    }
+    // best response per node (:757-775) = the best of its buckets' winners (k_compact)
+    const uint2 *win = reinterpret_cast<const uint2 *>(tb + tbl_win_off(g.bucketTotal)) + L.bucket0;
+    const uint2 *list = S.list[cur];
+    for (int i = lane; i < n; i += 64) {
+        const uint2 nd = list[i];
+        const int sh = 2 * (D - node_depth(nd));
+        const int b0 = (int)(node_code(nd) << sh), nb = 1 << sh;
+        uint32_t bestKey = 0, bestVal = 0;
+        for (int b = 0; b < nb; b++) {
+            const uint2 w = win[b0 + b];
+            if (w.x > bestKey) { bestKey = w.x; bestVal = w.y; }
+        }
+        oval[i] = bestVal;
+    }
+    if (lane == 0) *ocnt = n;
+}
+
+// ORBextractor::operator()'s assembly (:1103-1170) for one image per wave: levels in order, every level's keypoints in
+// DistributeOctTree's order; keypoints whose scaled x lies in [lap0, lap1] fill the output from the back (stereo), the others from
+// the front (mono).  sel[img][pos] = level | y | x (what the descriptor kernel reads), resp[img][pos] = FAST response,
+// nsel[img] = total, mono[img] = monoIndex.  An image with a level the GPU could not select gets nsel = 0.
+struct AssembleParams { float scale[kMaxLevels]; int lap0, lap1; };
+__global__ __launch_bounds__(64) void k_assemble(const uint32_t *__restrict__ sel_val, const int *__restrict__ sel_cnt, Geom g, AssembleParams P, int selcap,
+                                                 uint32_t *__restrict__ sel, uint8_t *__restrict__ resp, int *__restrict__ nsel, int *__restrict__ mono,
+                                                 int *__restrict__ fallback)
+{
+    const int lane = sel_lane(), img = blockIdx.x;
+    const int *cnt = sel_cnt + (size_t)img * g.nlevels;
+    int total = 0, bad = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int c = cnt[l];
+        if (c < 0) bad = 1; else total += c;
+    }
+    if (!bad && total > g.kcap) { bad = 1; if (lane == 0) atomicOr(fallback, 2); }
+    if (bad) {
+        if (lane == 0) { nsel[img] = 0; mono[img] = 0; }
+        return;
+    }
+    uint32_t *so = sel + (size_t)img * g.kcap;
+    uint8_t *ro = resp + (size_t)img * g.kcap;
+    int monoIndex = 0, stereoIndex = total - 1;
+    for (int l = 0; l < g.nlevels; l++) {
+        const uint32_t *v = sel_val + ((size_t)img * g.nlevels + l) * selcap;
+        const int c = cnt[l];
+        for (int c0 = 0; c0 < c; c0 += 64) {
+            const int i = c0 + lane;
+            const bool valid = i < c;
+            const uint32_t cd = valid ? v[i] : 0u;
+            const int xl = cand_x(cd) + kMinBorder, yl = cand_y(cd) + kMinBorder;
+            float kx = (float)xl;
+            if (l != 0) kx = __fmul_rn(kx, P.scale[l]);
+            const bool stereo = valid && kx >= (float)P.lap0 && kx <= (float)P.lap1;
+            const unsigned long long bs = __ballot(stereo), bm = __ballot(valid && !stereo);
+            if (valid) {
+                const int pos = stereo ? stereoIndex - sel_rank(bs) : monoIndex + sel_rank(bm);
+                so[pos] = pack_sel(l, xl, yl);
+                ro[pos] = (uint8_t)cand_resp(cd);
+            }
+            stereoIndex -= __popcll(bs);
+            monoIndex += __popcll(bm);
+        }
+    }
+    if (lane == 0) { nsel[img] = total; mono[img] = monoIndex; }
+}
+
+// --- launch wrappers -------------------------------------------------------------------------------------------------------------
+
+int select_cap(const Geom &g)   // retained candidates per (image, level): DistributeOctTree stops at N .. N + 2 nodes
+{
+    int q = 1;
+    for (int l = 0; l < g.nlevels; l++) q = q > g.lv[l].quota ? q : g.lv[l].quota;
+    return (q + 64 + 63) & ~63;
+}
+
+hipError_t launch_select(hipStream_t st, const int *tbl, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg)
+{
+    int B = 1;
+    for (int l = 0; l < g.nlevels; l++) B = B > g.lv[l].nBuckets ? B : g.lv[l].nBuckets;
+    const int cap = select_cap(g);
+    const size_t lds = sel_lds_bytes(B, cap);
+    if (cap > 65535 || lds > 160 * 1024) return hipErrorInvalidValue;
+    static size_t configured = 0;
+    if (lds > 64 * 1024 && lds > configured) {
+        const hipError_t e = hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        configured = lds;
+    }
+    hipLaunchKernelGGL(k_select, dim3(nimg, g.nlevels), dim3(64), lds, st, tbl, g, sel_val, sel_cnt, cap, B, cap, fallback);
+    return hipGetLastError();
+}
+
+void launch_assemble(hipStream_t st, const uint32_t *sel_val, const int *sel_cnt, const Geom &g, const float *scale, int lap0, int lap1,
+                     uint32_t *sel, uint8_t *resp, int *nsel, int *mono, int *fallback, int nimg)
+{
+    AssembleParams P;
+    for (int l = 0; l < kMaxLevels; l++) P.scale[l] = l < g.nlevels ? scale[l] : 1.f;
+    P.lap0 = lap0; P.lap1 = lap1;
+    hipLaunchKernelGGL(k_assemble, dim3(nimg), dim3(64), 0, st, sel_val, sel_cnt, g, P, select_cap(g), sel, resp, nsel, mono, fallback);
+}
+
+// test hook (mcorb_dev_sort_selftest): one wave sorts n entries with wave_std_sort
+__global__ __launch_bounds__(64) void k_sort_selftest(const uint64_t *__restrict__ in, int n, uint64_t *__restrict__ out, int cap)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sel_sh[];
+    SelLds S;
+    uint8_t *p = sel_sh;
+    S.bst = reinterpret_cast<int *>(p); p += 16;
+    S.list[0] = S.list[1] = nullptr;
+    S.exp[0] = reinterpret_cast<uint64_t *>(p); p += (size_t)cap * 8;
+    S.exp[1] = reinterpret_cast<uint64_t *>(p); p += (size_t)cap * 8;
+    S.blk = reinterpret_cast<uint32_t *>(p); p += (size_t)cap * 4;
+    S.ta = reinterpret_cast<uint16_t *>(p); p += (size_t)cap * 2;
+    S.tb = reinterpret_cast<uint16_t *>(p); p += (size_t)cap * 2;
+    S.stk = reinterpret_cast<int *>(p);
+    for (int i = sel_lane(); i < n; i += 64) S.exp[0][i] = in[i];
+    sel_sync();
+    wave_std_sort(S.exp[0], n, S.exp[1], S);
+    for (int i = sel_lane(); i < n; i += 64) out[i] = S.exp[1][i];
+}
+
+hipError_t sort_selftest(const uint64_t *in_dev, int n, uint64_t *out_dev)
+{
+    const int cap = (n + 63) & ~63;
+    const size_t lds = 16 + (size_t)cap * (8 + 8 + 4 + 2 + 2) + kSelStack * 4;
+    if (n < 0 || cap > 6000 || lds > 160 * 1024) return hipErrorInvalidValue;
+    if (lds > 64 * 1024) {
+        const hipError_t e = hipFuncSetAttribute((const void *)k_sort_selftest, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_sort_selftest, dim3(1), dim3(64), lds, 0, in_dev, n, out_dev, cap);
+    return hipDeviceSynchronize();
+}
+
+}  // namespace mcorb

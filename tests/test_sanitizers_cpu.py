@@ -20,3 +20,17 @@ def test_host_selection_under_asan_ubsan():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "bad=0" in out.stdout
+
+
+def test_sort_model_equals_std_sort():
+    """mcorb_sortmodel.h -- libstdc++'s std::sort as the GPU selection kernel runs it (closed-form partition, independent
+    sub-ranges, block-wise stable finish, shared heap sort) -- against std::sort itself: 12 000 random multisets full of ties,
+    structured sequences, and median-of-three killers that force the heap-sort branch (asserted to have been taken)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_sortmodel")
+    src = [os.path.join(ROOT, "tests", "cpp", "test_sortmodel.cpp"), os.path.join(ROOT, "mc-slam_amd", "csrc", "mcorb_sortmodel.h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                               "-I" + os.path.join(ROOT, "mc-slam_amd", "csrc"), src[0], "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "bad=0" in out.stdout and "heap_cases=0" not in out.stdout
