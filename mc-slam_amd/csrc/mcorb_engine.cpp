@@ -475,7 +475,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         int mode = p.selection;
         if (mode == MCORB_SELECT_AUTO && e) mode = !strcmp(e, "host") ? MCORB_SELECT_HOST : (!strcmp(e, "gpu") ? MCORB_SELECT_GPU : MCORB_SELECT_AUTO);
         if (mode != MCORB_SELECT_AUTO && mode != MCORB_SELECT_HOST && mode != MCORB_SELECT_GPU) { set_error("mcorb_params.selection: unknown mode"); return MCORB_E_ARG; }
-        gpu_select = mode != MCORB_SELECT_HOST;
+        gpu_select = mode != MCORB_SELECT_HOST && select_fits(geom);   // (mcorb_rig_select_mode reports what the rig really runs)
     }
     pool = new WorkerPool(nthreads);
     pool_threads = nthreads;

@@ -70,6 +70,7 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
 // stage (fallback |= 1); sel / nsel: what the descriptor kernel and the matcher read; resp / mono: FAST responses and monoIndex
 // for the host's keypoint records; fallback bit 1 = more than kcap keypoints.
 int select_cap(const Geom &g);
+bool select_fits(const Geom &g);   // false: the level trees of this geometry do not fit a wave's LDS (very large feature budgets)
 hipError_t launch_select(hipStream_t st, const int *tbl, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg);
 void launch_assemble(hipStream_t st, const uint32_t *sel_val, const int *sel_cnt, const Geom &g, const float *scale, int lap0, int lap1,
                      uint32_t *sel, uint8_t *resp, int *nsel, int *mono, int *fallback, int nimg);

@@ -42,17 +42,13 @@ __device__ __forceinline__ void sel_sync()   // LDS written by some lanes of thi
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ int sel_uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-__device__ __forceinline__ int sel_scan(int v)   // inclusive prefix sum over the wave
+// inclusive prefix sum over the wave for values 0 .. 7 (children per node): three ballots, no cross-lane traffic; tot = the wave's sum
+__device__ __forceinline__ int sel_scan3(int v, int &tot)
 {
-    const int lane = sel_lane();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
-    return v;
+    const unsigned long long b0 = __ballot(v & 1), b1 = __ballot(v & 2), b2 = __ballot(v & 4);
+    tot = __popcll(b0) + 2 * __popcll(b1) + 4 * __popcll(b2);
+    return sel_rank(b0) + 2 * sel_rank(b1) + 4 * sel_rank(b2) + v;
 }
-__device__ __forceinline__ int sel_total(int incl) { return __shfl(incl, 63); }
 
 // a tree node: x = path code | depth << 24, y = UL.x | UR.x << 16 (level coordinates relative to minX; the y extent is not needed:
 // only UL.x enters compareNodes, and the key sets come from the bucket table)
@@ -89,6 +85,7 @@ __device__ __forceinline__ uint32_t kids_info(const int cnt[4])
 
 struct SelLds {
     int *bst;                 // bucket starts of this level (B + 1)
+    const uint2 *win;         // the buckets' winners {key, candidate} (k_compact), staged while the tree is built
     uint2 *list[2];           // node lists, ping-pong
     uint64_t *exp[2];         // (key count << 12 | UL.x) << 32 | list position of the nodes that can still be divided
     uint16_t *ta, *tb;        // scratch: partition positions (sort) / per-node and per-entry division summaries (passes)
@@ -96,7 +93,7 @@ struct SelLds {
     int *stk;                 // sort: range stack
 };
 constexpr int kSelStack = 3 * 48;
-__host__ __device__ inline size_t sel_lds_bytes(int B, int cap) { return (size_t)(B + 1 + 3) / 4 * 16 + (size_t)cap * (2 * 8 + 2 * 8 + 2 * 2 + 4) + kSelStack * 4; }
+__host__ __device__ inline size_t sel_lds_bytes(int B, int cap) { return (size_t)(B + 1 + 3) / 4 * 16 + (size_t)(B + 1) / 2 * 16 + (size_t)cap * (2 * 8 + 2 * 8 + 2 * 2 + 4) + kSelStack * 4; }
 
 // std::sort(a, a + n) on the upper halves, libstdc++'s permutation (mcorb_sortmodel.h); the result is in `out`
 __device__ void wave_std_sort(uint64_t *a, int n, uint64_t *out, SelLds &S)
@@ -209,7 +206,9 @@ __device__ int full_pass(const SelLds &S, const uint2 *in, int n, uint2 *out, ui
             }
             info[i] = (uint16_t)inf;
         }
-        H += sel_total(sel_scan(nc));
+        int tot;
+        (void)sel_scan3(nc, tot);
+        H += tot;
         singles += __popcll(__ballot(!(inf & 0x100u)));
     }
     if (__ballot(bad != 0) != 0ull || H + singles > cap) { fb = 1; m = 0; return n; }
@@ -220,7 +219,8 @@ __device__ int full_pass(const SelLds &S, const uint2 *in, int n, uint2 *out, ui
         const uint32_t inf = i < n ? info[i] : 0u;
         const uint32_t mask = inf & 15u, emask = (inf >> 4) & 15u;
         const int nc = __popc(mask), ne = __popc(emask);
-        const int cin = sel_scan(nc), ein = sel_scan(ne);
+        int ctot, etot;
+        const int cin = sel_scan3(nc, ctot), ein = sel_scan3(ne, etot);
         const bool single = i < n && !(inf & 0x100u);
         const unsigned long long bs = __ballot(single);
         if (inf & 0x100u) {
@@ -240,8 +240,8 @@ __device__ int full_pass(const SelLds &S, const uint2 *in, int n, uint2 *out, ui
         } else if (single) {
             out[H + sel_rank(bs, trun)] = in[i];
         }
-        crun += sel_total(cin);
-        erun += sel_total(ein);
+        crun += ctot;
+        erun += etot;
         trun += __popcll(bs);
     }
     sel_sync();
@@ -272,12 +272,13 @@ __device__ int careful_round(const SelLds &S, const uint2 *in, int n, uint2 *out
                 inf = kids_info(cnt);
             }
             einfo[t] = (uint16_t)inf;
-            inc = __popc(inf & 15u) - 1;
+            inc = __popc(inf & 15u);
         }
-        const int sin = sel_scan(inc);
+        int itot;
+        const int sin = sel_scan3(inc, itot) - (lane + 1);   // a division replaces one node by its non-empty children
         const unsigned long long reach = __ballot(t < m && n + srun + sin >= N);
         if (reach) k = t0 + (int)__builtin_ctzll(reach) + 1;
-        srun += sel_total(sin);
+        srun += itot - min(64, m - t0);
     }
     if (k < 0) k = m;
     sel_sync();
@@ -286,7 +287,9 @@ __device__ int careful_round(const SelLds &S, const uint2 *in, int n, uint2 *out
     for (int t0 = 0; t0 < k; t0 += 64) {
         const int t = t0 + lane;
         const uint32_t inf = t < k ? einfo[t] : 0u;
-        Hc += sel_total(sel_scan(__popc(inf & 15u)));
+        int tot;
+        (void)sel_scan3(__popc(inf & 15u), tot);
+        Hc += tot;
     }
     {
         int badk = 0;
@@ -303,7 +306,8 @@ __device__ int careful_round(const SelLds &S, const uint2 *in, int n, uint2 *out
         const uint32_t inf = t < k ? einfo[t] : 0u;
         const uint32_t mask = inf & 15u, emask = (inf >> 4) & 15u;
         const int nc = __popc(mask), ne = __popc(emask);
-        const int cin = sel_scan(nc), ein = sel_scan(ne);
+        int ctot, etot;
+        const int cin = sel_scan3(nc, ctot), ein = sel_scan3(ne, etot);
         if (t < k) {
             const uint32_t pos0 = (uint32_t)srt[m - 1 - t];
             const uint2 nd = in[pos0];
@@ -321,8 +325,8 @@ __device__ int careful_round(const SelLds &S, const uint2 *in, int n, uint2 *out
                     exp[eexcl + __popc(emask & ((1u << q) - 1u))] = ((uint64_t)(((uint32_t)cnt[q] << 12) | (ch.y & 0xffffu)) << 32) | (uint32_t)pos;
             }
         }
-        crun += sel_total(cin);
-        erun += sel_total(ein);
+        crun += ctot;
+        erun += etot;
     }
     sel_sync();
     int trun = 0;
@@ -362,6 +366,7 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom
     {
         uint8_t *p = sel_sh;
         S.bst = reinterpret_cast<int *>(p); p += (size_t)(ldsB + 1 + 3) / 4 * 16;
+        S.win = reinterpret_cast<const uint2 *>(p); p += (size_t)(ldsB + 1) / 2 * 16;
         S.list[0] = reinterpret_cast<uint2 *>(p); p += (size_t)cap * 8;
         S.list[1] = reinterpret_cast<uint2 *>(p); p += (size_t)cap * 8;
         S.exp[0] = reinterpret_cast<uint64_t *>(p); p += (size_t)cap * 8;
@@ -371,8 +376,15 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom
         S.tb = reinterpret_cast<uint16_t *>(p); p += (size_t)cap * 2;
         S.stk = reinterpret_cast<int *>(p);
     }
-    const int *bsrc = tb + kTblHead + L.bucket0;
-    for (int b = lane; b <= B; b += 64) S.bst[b] = bsrc[b];
+    // the level's bucket starts and bucket winners: global -> LDS, all loads in flight at once (the winners are not needed before
+    // the tree is finished)
+    {
+        const int *bsrc = tb + kTblHead + L.bucket0;
+        const uint2 *wsrc = reinterpret_cast<const uint2 *>(tb + tbl_win_off(g.bucketTotal)) + L.bucket0;
+        uint2 *wdst = const_cast<uint2 *>(S.win);
+        for (int b = lane; b <= B; b += 64) S.bst[b] = bsrc[b];
+        for (int b = lane; b < B; b += 64) wdst[b] = wsrc[b];
+    }
     sel_sync();
     // root nodes (:567-600): empty ones are erased
     int n, m = 0, fb = 0, cur = 0;
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom
         return;
     }
     // best response per node (:757-775) = the best of its buckets' winners (k_compact)
-    const uint2 *win = reinterpret_cast<const uint2 *>(tb + tbl_win_off(g.bucketTotal)) + L.bucket0;
+    const uint2 *win = S.win;
     const uint2 *list = S.list[cur];
     for (int i = lane; i < n; i += 64) {
         const uint2 nd = list[i];
@@ -434,52 +446,68 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom
     if (lane == 0) *ocnt = n;
 }
 
-// ORBextractor::operator()'s assembly (:1103-1170) for one image per wave: levels in order, every level's keypoints in
+// ORBextractor::operator()'s assembly (:1103-1170), one workgroup per image, one wave per level: levels in order, every level's keypoints in
 // DistributeOctTree's order; keypoints whose scaled x lies in [lap0, lap1] fill the output from the back (stereo), the others from
 // the front (mono).  sel[img][pos] = level | y | x (what the descriptor kernel reads), resp[img][pos] = FAST response,
 // nsel[img] = total, mono[img] = monoIndex.  An image with a level the GPU could not select gets nsel = 0.
 struct AssembleParams { float scale[kMaxLevels]; int lap0, lap1; };
-__global__ __launch_bounds__(64) void k_assemble(const uint32_t *__restrict__ sel_val, const int *__restrict__ sel_cnt, Geom g, AssembleParams P, int selcap,
-                                                 uint32_t *__restrict__ sel, uint8_t *__restrict__ resp, int *__restrict__ nsel, int *__restrict__ mono,
-                                                 int *__restrict__ fallback)
+__global__ __launch_bounds__(64 * kMaxLevels) void k_assemble(const uint32_t *__restrict__ sel_val, const int *__restrict__ sel_cnt, Geom g, AssembleParams P,
+                                                               int selcap, uint32_t *__restrict__ sel, uint8_t *__restrict__ resp, int *__restrict__ nsel,
+                                                               int *__restrict__ mono, int *__restrict__ fallback)
 {
-    const int lane = sel_lane(), img = blockIdx.x;
-    const int *cnt = sel_cnt + (size_t)img * g.nlevels;
-    int total = 0, bad = 0;
-    for (int l = 0; l < g.nlevels; l++) {
-        const int c = cnt[l];
-        if (c < 0) bad = 1; else total += c;
+    // one workgroup per image, one wave per level: every wave counts its level's stereo keypoints, the counts of the levels before
+    // it give its first mono / stereo position
+    __shared__ int s_cnt[kMaxLevels], s_st[kMaxLevels];
+    const int lane = sel_lane(), level = threadIdx.x >> 6, img = blockIdx.x;
+    const int c = sel_cnt[(size_t)img * g.nlevels + level];
+    const uint32_t *v = sel_val + ((size_t)img * g.nlevels + level) * selcap;
+    const float sc = P.scale[level], lo = (float)P.lap0, hi = (float)P.lap1;
+    auto is_stereo = [&](uint32_t cd) {
+        float kx = (float)(cand_x(cd) + kMinBorder);
+        if (level != 0) kx = __fmul_rn(kx, sc);
+        return kx >= lo && kx <= hi;
+    };
+    int nst = 0;
+    for (int c0 = 0; c0 < c; c0 += 64) {
+        const int i = c0 + lane;
+        nst += __popcll(__ballot(i < c && is_stereo(v[min(i, c - 1)])));
     }
-    if (!bad && total > g.kcap) { bad = 1; if (lane == 0) atomicOr(fallback, 2); }
-    if (bad) {
-        if (lane == 0) { nsel[img] = 0; mono[img] = 0; }
+    if (lane == 0) { s_cnt[level] = c; s_st[level] = nst; }
+    __syncthreads();
+    int total = 0, bad = 0, monoBefore = 0, stereoBefore = 0, monoAll = 0;
+    for (int l = 0; l < g.nlevels; l++) {
+        const int cl = s_cnt[l];
+        if (cl < 0) { bad = 1; continue; }
+        total += cl;
+        monoAll += cl - s_st[l];
+        if (l < level) { monoBefore += cl - s_st[l]; stereoBefore += s_st[l]; }
+    }
+    if (!bad && total > g.kcap) {
+        bad = 1;
+        if (threadIdx.x == 0) atomicOr(fallback, 2);
+    }
+    if (bad) {   // a level the GPU could not select (or too many keypoints): the host stage redoes the batch
+        if (threadIdx.x == 0) { nsel[img] = 0; mono[img] = 0; }
         return;
     }
     uint32_t *so = sel + (size_t)img * g.kcap;
     uint8_t *ro = resp + (size_t)img * g.kcap;
-    int monoIndex = 0, stereoIndex = total - 1;
-    for (int l = 0; l < g.nlevels; l++) {
-        const uint32_t *v = sel_val + ((size_t)img * g.nlevels + l) * selcap;
-        const int c = cnt[l];
-        for (int c0 = 0; c0 < c; c0 += 64) {
-            const int i = c0 + lane;
-            const bool valid = i < c;
-            const uint32_t cd = valid ? v[i] : 0u;
-            const int xl = cand_x(cd) + kMinBorder, yl = cand_y(cd) + kMinBorder;
-            float kx = (float)xl;
-            if (l != 0) kx = __fmul_rn(kx, P.scale[l]);
-            const bool stereo = valid && kx >= (float)P.lap0 && kx <= (float)P.lap1;
-            const unsigned long long bs = __ballot(stereo), bm = __ballot(valid && !stereo);
-            if (valid) {
-                const int pos = stereo ? stereoIndex - sel_rank(bs) : monoIndex + sel_rank(bm);
-                so[pos] = pack_sel(l, xl, yl);
-                ro[pos] = (uint8_t)cand_resp(cd);
-            }
-            stereoIndex -= __popcll(bs);
-            monoIndex += __popcll(bm);
+    int monoIndex = monoBefore, stereoIndex = total - 1 - stereoBefore;
+    for (int c0 = 0; c0 < c; c0 += 64) {
+        const int i = c0 + lane;
+        const bool valid = i < c;
+        const uint32_t cd = valid ? v[i] : 0u;
+        const bool stereo = valid && is_stereo(cd);
+        const unsigned long long bs = __ballot(stereo), bm = __ballot(valid && !stereo);
+        if (valid) {
+            const int pos = stereo ? stereoIndex - sel_rank(bs) : monoIndex + sel_rank(bm);
+            so[pos] = pack_sel(level, cand_x(cd) + kMinBorder, cand_y(cd) + kMinBorder);
+            ro[pos] = (uint8_t)cand_resp(cd);
         }
+        stereoIndex -= __popcll(bs);
+        monoIndex += __popcll(bm);
     }
-    if (lane == 0) { nsel[img] = total; mono[img] = monoIndex; }
+    if (threadIdx.x == 0) { nsel[img] = total; mono[img] = monoAll; }
 }
 
 // --- launch wrappers -------------------------------------------------------------------------------------------------------------
@@ -491,13 +519,29 @@ int select_cap(const Geom &g)   // retained candidates per (image, level): Distr
     return (q + 64 + 63) & ~63;
 }
 
+static size_t select_lds(const Geom &g, int &B)
+{
+    B = 1;
+    for (int l = 0; l < g.nlevels; l++) B = B > g.lv[l].nBuckets ? B : g.lv[l].nBuckets;
+    return sel_lds_bytes(B, select_cap(g));
+}
+
+// k_select keeps a level's tree, its sort scratch and its bucket tables in one wave's LDS: feature budgets beyond ~2 500 per
+// level (or more than 64 root nodes) do not fit 160 KiB -- such rigs select on the host
+bool select_fits(const Geom &g)
+{
+    int B;
+    for (int l = 0; l < g.nlevels; l++)
+        if (g.lv[l].nIni > 64) return false;
+    return select_cap(g) <= 65535 && select_lds(g, B) <= 160 * 1024;
+}
+
 hipError_t launch_select(hipStream_t st, const int *tbl, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg)
 {
-    int B = 1;
-    for (int l = 0; l < g.nlevels; l++) B = B > g.lv[l].nBuckets ? B : g.lv[l].nBuckets;
+    int B;
     const int cap = select_cap(g);
-    const size_t lds = sel_lds_bytes(B, cap);
-    if (cap > 65535 || lds > 160 * 1024) return hipErrorInvalidValue;
+    const size_t lds = select_lds(g, B);
+    if (!select_fits(g)) return hipErrorInvalidValue;
     static size_t configured = 0;
     if (lds > 64 * 1024 && lds > configured) {
         const hipError_t e = hipFuncSetAttribute((const void *)k_select, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -514,7 +558,7 @@ void launch_assemble(hipStream_t st, const uint32_t *sel_val, const int *sel_cnt
     AssembleParams P;
     for (int l = 0; l < kMaxLevels; l++) P.scale[l] = l < g.nlevels ? scale[l] : 1.f;
     P.lap0 = lap0; P.lap1 = lap1;
-    hipLaunchKernelGGL(k_assemble, dim3(nimg), dim3(64), 0, st, sel_val, sel_cnt, g, P, select_cap(g), sel, resp, nsel, mono, fallback);
+    hipLaunchKernelGGL(k_assemble, dim3(nimg), dim3(64 * g.nlevels), 0, st, sel_val, sel_cnt, g, P, select_cap(g), sel, resp, nsel, mono, fallback);
 }
 
 // test hook (mcorb_dev_sort_selftest): one wave sorts n entries with wave_std_sort
