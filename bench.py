@@ -194,6 +194,10 @@ def main():
                     help="N > 1: frames = frame f matched on rank f mod N; pairs = camera pair (i, j) of frame f matched on rank "
                          "(i + j + f) mod N, the accepted lists gathered on rank 0, which runs the serial track merge")
     ap.add_argument("--dump-tracks", default=None, help="(tests) write the tracks of this rank's first frames to an .npz")
+    ap.add_argument("--graph", type=int, default=None,
+                    help="mcorb_rig_set_graph: 0 = every job launch by launch, 1 = every job replayed from its HIP graph (no per-kernel "
+                         "events: the roofline figures fall back to the isolated durations), K > 1 = all but every K-th job of a slot, "
+                         "which is the timed sample (default: the engine's)")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the two child-process legs of the N = 1 line: value_force_dist (the sharded path at world size 1, the "
                          "like-for-like denominator of value(N) / (N value(1))) and configs2_1080p8 (BASELINE configs[2] on one GPU)")
@@ -263,7 +267,9 @@ def main():
         raise SystemExit("supported combinations: --exchange a2a --partition frames (default), --exchange allgather --partition pairs")
     if PAIRS:
         os.environ.setdefault("MCORB_BENCH_GROUPS", "1")   # the literal 8(e) path is run round by round, not pipelined
-    S = args.slots if args.slots else ((2 if PAIRS else 12) if DIST else 6)
+    # jobs in flight: with the selection on the GPU a job is one submission and five are enough (six measured 3 - 8 % slower:
+    # profiles/r04_slots.txt); the host selection needs a sixth to hide its round trip
+    S = args.slots if args.slots else ((2 if PAIRS else 12) if DIST else (6 if os.environ.get("MCORB_SELECT") == "host" else 5))
     G = int(os.environ.get("MCORB_BENCH_GROUPS", "6")) if DIST else 1   # slot groups: with N > 1 G-1 groups extract ahead while one is matched
     IT = 2 if DIST else 1              # exchange rounds per step on the N > 1 path (one round = one group = SG slot jobs per rank)
     if DIST and S % G:
@@ -277,6 +283,8 @@ def main():
     # (several ranks share the node's CPUs: the engine divides its core budget by LOCAL_WORLD_SIZE and its slot drivers poll
     # their events with short sleeps instead of spinning, so nothing has to be set here)
     rig = mcorb.Rig(NCAMS, W, H, max_frames=fps, nslots=S, nfeatures=NFEAT, device_id=local)
+    if args.graph is not None:
+        rig.set_graph(args.graph)
     kcap = rig.kcap
     total_frames = F * N               # rig frames per exchange round over all ranks (N = 1: per step)
 
@@ -468,8 +476,13 @@ def main():
     # per-kernel durations, accumulated from the HIP events the engine records on each slot's stream
     ksum = {k: 0.0 for k in TIMING_FIELD}
 
+    ksamples = [0]
+
     def account(s):
         t = rig.timing(slot=s)
+        if t["fast_us"] <= 0:      # a job replayed from its graph has no per-kernel events: not a sample
+            return
+        ksamples[0] += 1
         for k, f in TIMING_FIELD.items():
             ksum[k] += t[f]
 
@@ -588,6 +601,7 @@ def main():
     iso = None
     if not DIST:
         acc = {k: [] for k in TIMING_FIELD}
+        rig.set_graph(0)           # launch by launch: every kernel between its own HIP events
         for _ in range(args.iso_jobs):
             rig.process_submit(fps, slot=0)
             rig.process_wait(slot=0)
@@ -597,7 +611,8 @@ def main():
         iso = {k: float(np.median(v)) for k, v in acc.items()}
     rank_by = {k: (iso or ksum)[k] for k in GPU_KERNELS}
     dominant = max(rank_by, key=rank_by.get)
-    avg_us = ksum[dominant] / launches
+    sampled = max(1, ksamples[0])            # jobs of the timed regions that ran launch by launch (all of them unless graphs are on)
+    avg_us = ksum[dominant] / sampled if ksamples[0] else (iso[dominant] if iso else 0.0)
     units = pairs_launch if dominant == "k_knn2" else nimg_launch
     unit_bytes = algorithmic_bytes(dominant, Spx, S0, s_last, K, Kc, info["bucket_total"])
     achieved = unit_bytes * units / (avg_us * 1e-6) / 1e9 if avg_us > 0 else 0.0
@@ -639,7 +654,10 @@ def main():
                      "images_per_launch": nimg_launch, "fast_candidates_per_image": int(Kc),
                      "note": "avg_launch_us is the HIP-event average over the timed regions, where %d jobs share the GPU; "
                              "isolated_* is the same kernel with one job in flight (median of %d)" % (S, args.iso_jobs)},
-        "kernel_us_per_step": {k: round(v / args.steps / len(dts), 2) for k, v in ksum.items()},
+        "kernel_us_per_step": {k: round(v / sampled * launches / args.steps / len(dts), 2) for k, v in ksum.items()},
+        "kernel_timing_samples": {"jobs_sampled": ksamples[0], "jobs_timed": launches,
+                                  "note": "jobs that ran launch by launch with per-kernel HIP events inside the timed regions; the others were replayed "
+                                          "from their captured HIP graph (mcorb_rig_set_graph)"},
     }
     # the whole path against the HBM roof: SURVEY 8(d)'s bytes per rig frame (every plane once per logical pass, the blur's
     # 2 S included although this build no longer moves them) and the bytes this build's kernels really have to move

@@ -176,6 +176,12 @@ int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[10]);
 /* MCORB_SELECT_HOST or MCORB_SELECT_GPU: what this rig runs; jobs of a slot that fell back to the host stage so far */
 int mcorb_rig_select_mode(mcorb_rig *r);
 int mcorb_rig_select_fallbacks(mcorb_rig *r, int slot);
+/* MCORB_SELECT_GPU only: a job is the same ~20 launches and copies every time, so a slot captures it once into a HIP graph and
+ * replays it with one call.  every = 0: never (launch by launch, per-kernel HIP events: mcorb_rig_last_timing is complete),
+ * 1: every job (last_timing reports [0] = the whole job, the rest 0), K > 1: all but every K-th job of a slot, which runs
+ * launch by launch -- a timed sample of the same pipeline.  Default: the environment's MCORB_GRAPH, else 1 for a rig with one slot
+ * (one job at a time: the replay saves ~60 us of a 0.4 ms rig frame) and 0 otherwise (with several jobs in flight it measured slower). */
+int mcorb_rig_set_graph(mcorb_rig *r, int every);
 /* test hook for the GPU selection's sort: the permutation std::sort (libstdc++) leaves n keys in, computed by one GPU wave
  * (perm_dev) and by std::sort itself on the host (perm_std); entries compare by key only (mcorb_sortmodel.h) */
 int mcorb_dev_sort_selftest(int device, const uint32_t *keys, int n, uint32_t *perm_dev, uint32_t *perm_std);

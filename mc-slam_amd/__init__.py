@@ -306,6 +306,10 @@ class Rig:
         """'gpu' (DistributeOctTree's list discipline in k_select: a job is one submission) or 'host' (worker pool between two GPU phases)"""
         return {1: "host", 2: "gpu"}[self.L.mcorb_rig_select_mode(self.h_rig)]
 
+    def set_graph(self, every):
+        """replay GPU-selected jobs from a captured HIP graph: 0 never, 1 always, K > 1 all but every K-th job of a slot"""
+        _lib.check(self.L.mcorb_rig_set_graph(self.h_rig, every))
+
     def select_fallbacks(self, slot=0):
         """jobs of the slot the host stage had to redo (a level whose tree went below the GPU bucketing depth)"""
         return int(self.L.mcorb_rig_select_fallbacks(self.h_rig, slot))

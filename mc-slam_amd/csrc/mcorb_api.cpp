@@ -390,6 +390,12 @@ int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[10])
 
 int mcorb_rig_kcap(mcorb_rig *r) { return r ? r->rig.geom.kcap : MCORB_E_ARG; }
 int mcorb_rig_select_mode(mcorb_rig *r) { return r ? (r->rig.gpu_select ? MCORB_SELECT_GPU : MCORB_SELECT_HOST) : MCORB_E_ARG; }
+int mcorb_rig_set_graph(mcorb_rig *r, int every)
+{
+    if (!r || every < 0) return MCORB_E_ARG;
+    r->rig.graph_every.store(r->rig.gpu_select ? every : 0);
+    return MCORB_OK;
+}
 int mcorb_rig_select_fallbacks(mcorb_rig *r, int slot)
 {
     if (!r || slot < 0 || slot >= (int)r->rig.slots.size()) return MCORB_E_ARG;

@@ -475,7 +475,10 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         int mode = p.selection;
         if (mode == MCORB_SELECT_AUTO && e) mode = !strcmp(e, "host") ? MCORB_SELECT_HOST : (!strcmp(e, "gpu") ? MCORB_SELECT_GPU : MCORB_SELECT_AUTO);
         if (mode != MCORB_SELECT_AUTO && mode != MCORB_SELECT_HOST && mode != MCORB_SELECT_GPU) { set_error("mcorb_params.selection: unknown mode"); return MCORB_E_ARG; }
-        gpu_select = mode != MCORB_SELECT_HOST && select_fits(geom);   // (mcorb_rig_select_mode reports what the rig really runs)
+        gpu_select = mode != MCORB_SELECT_HOST && select_fits(geom);
+        // HIP graphs: a single-slot rig (one job at a time, how MC-SLAM calls) replays its job from a captured graph -- 0.41 -> 0.35 ms
+        // per rig frame; with several jobs in flight the replay measured 3 - 5 % SLOWER than launch by launch (profiles/r04_graph.txt)
+        graph_every = !gpu_select ? 0 : getenv("MCORB_GRAPH") ? std::max(0, atoi(getenv("MCORB_GRAPH"))) : (nslots == 1 ? 1 : 0);   // (mcorb_rig_select_mode reports what the rig really runs)
     }
     pool = new WorkerPool(nthreads);
     pool_threads = nthreads;
@@ -556,6 +559,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
             TRY(host_alloc(&s->h_res, s->res_bytes));
             HIPCHK(hipMemset(s->d_res, 0, s->res_bytes));
             HIPCHK(hipEventCreateWithFlags(&s->ev_s, hipEventDefault));
+            HIPCHK(hipEventCreateWithFlags(&s->ev_g, hipEventDefault));
         }
         TRY(host_alloc(&s->h_stage, M * (size_t)W * H));
         TRY(host_alloc(&s->h_desc, M * geom.kcap * 32));
@@ -600,6 +604,8 @@ Rig::~Rig()
         (void)hipHostFree(s->h_desc); (void)hipHostFree(s->h_angles);
         (void)hipFree(s->d_selval); (void)hipFree(s->d_selcnt); (void)hipFree(s->d_res); (void)hipHostFree(s->h_res);
         if (s->ev_s) (void)hipEventDestroy(s->ev_s);
+        if (s->ev_g) (void)hipEventDestroy(s->ev_g);
+        if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
         for (auto &e : s->ev) if (e) (void)hipEventDestroy(e);
         if (s->ev_x) (void)hipEventDestroy(s->ev_x);
         if (s->ev_c) (void)hipEventDestroy(s->ev_c);
@@ -1055,19 +1061,13 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
 // the host comes back when the results have landed (descriptors, the control block's sel / nsel, responses, monoIndex, flags) and
 // only builds its keypoint records from them.  A batch with a level whose tree goes below the bucketing depth (flag) is redone
 // through the host stage: run_select_and_describe on the tables, exactly the MCORB_SELECT_HOST path.
-int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
+// everything a GPU-selected job puts on the slot's streams, from the control block's head to the result copies
+int Rig::enqueue_gpu_job(Slot &s, const Job &j, bool then_match)
 {
-    if (j.nimg < 1 || j.nimg > max_images) { set_error("extract: bad image count"); return MCORB_E_ARG; }
     const int nimg = j.nimg;
-    s.invalidate_bow();
-    s.small_job = false;
-    s.h_overflow[0] = 0;
-    s.nimg_done = nimg;
-    if (then_match) {
-        // pair list / set map first: k_assemble overwrites the control block's nsel and sel afterwards, in stream order
-        TRY(prepare_match(s, j));
+    (void)hipGetLastError();   // (a stale error of this thread -- e.g. an elapsed-time query on an event a replayed graph never recorded -- is not this job's)
+    if (then_match)   // pair list / set map first: k_assemble overwrites the control block's nsel and sel afterwards, in stream order
         HIPCHK(hipMemcpyAsync(s.d_ctrl, s.h_ctrl, s.ctrl_pairs_end, hipMemcpyHostToDevice, s.st));
-    }
     int *d_flags = reinterpret_cast<int *>(s.d_res);
     HIPCHK(hipMemsetAsync(d_flags, 0, 16 * sizeof(int), s.st));
     HIPCHK(hipEventRecord(s.ev[0], s.st));
@@ -1082,7 +1082,6 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
                     reinterpret_cast<int *>(s.d_res + s.res_mono_off), d_flags, nimg);
     HIPCHK(hipEventRecord(s.ev_s, s.st));
     HIPCHK(hipEventRecord(s.ev[3], s.st));
-    s.blur_valid = blur_planes;
     if (blur_planes) launch_blur(s.st, s.d_pyr, s.d_blur, geom, nimg);
     HIPCHK(hipEventRecord(s.ev[4], s.st));
     HIPCHK(hipEventRecord(s.ev[5], s.st));
@@ -1100,16 +1099,64 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
         HIPCHK(hipMemcpyAsync(s.h_angles, s.d_angles, (size_t)nimg * geom.kcap * sizeof(float), hipMemcpyDeviceToHost, s.st_dma));
     if (then_match) TRY(enqueue_match(s, j, true));
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(s.ev[10], s.st));
     HIPCHK(hipEventRecord(s.ev[11], s.st_dma));
-    HIPCHK(wait_event(s.ev[10]));
-    HIPCHK(wait_event(s.ev[11]));
+    return MCORB_OK;
+}
+
+// MCORB_SELECT_GPU: the whole job -- pyramid, FAST, compaction, selection, assembly, descriptors, matching -- is enqueued in one go;
+// the host comes back when the results have landed (descriptors, the control block's sel / nsel, responses, monoIndex, flags) and
+// only builds its keypoint records from them.  A batch with a level whose tree goes below the bucketing depth (flag) is redone
+// through the host stage: run_select_and_describe on the tables, exactly the MCORB_SELECT_HOST path.
+int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
+{
+    if (j.nimg < 1 || j.nimg > max_images) { set_error("extract: bad image count"); return MCORB_E_ARG; }
+    const int nimg = j.nimg;
+    s.invalidate_bow();
+    s.small_job = false;
+    s.h_overflow[0] = 0;
+    s.nimg_done = nimg;
+    if (then_match) TRY(prepare_match(s, j));
+    s.blur_valid = blur_planes;
+    // The job is the same ~20 launches and copies every time: captured once per (slot, shape of the job) into a HIP graph and
+    // replayed with one call -- the CPU side of a job drops from ~20 runtime calls to one, the gaps between its kernels shrink.
+    // (Per-kernel HIP events do not exist inside a replayed graph: mcorb_rig_last_timing reports the job as a whole then.)
+    // graph_every: 0 = never, 1 = every job, K > 1 = all but every K-th job of a slot, which runs launch by launch with its
+    // per-kernel events (a sample of the same pipeline for mcorb_rig_last_timing)
+    const int ge = graph_every.load(std::memory_order_relaxed);
+    const bool graphed = ge > 0 && !j.ext_desc && (ge == 1 || (++s.job_counter % ge) != 0);
+    if (graphed) {
+        const Slot::GraphKey key{nimg, then_match ? 1 : 0, j.nframes, j.lap0, j.lap1, j.dist_thresh, j.ratio};
+        if (!s.graph_exec || memcmp(&key, &s.graph_key, sizeof(key)) != 0) {
+            if (s.graph_exec) { (void)hipGraphExecDestroy(s.graph_exec); s.graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(s.st, hipStreamCaptureModeThreadLocal));
+            int st = enqueue_gpu_job(s, j, then_match);
+            hipError_t e = hipStreamWaitEvent(s.st, s.ev[11], 0);   // the side stream joins again
+            const hipError_t e2 = hipStreamEndCapture(s.st, &graph);
+            if (st != MCORB_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+            if (e == hipSuccess) e = e2;
+            if (e == hipSuccess) e = hipGraphInstantiate(&s.graph_exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) { s.graph_exec = nullptr; set_error(std::string("graph capture: ") + hipGetErrorString(e)); return MCORB_E_HIP; }
+            s.graph_key = key;
+        }
+        HIPCHK(hipEventRecord(s.ev_g, s.st));
+        HIPCHK(hipGraphLaunch(s.graph_exec, s.st));
+        HIPCHK(hipEventRecord(s.ev[10], s.st));
+        HIPCHK(wait_event(s.ev[10]));
+    } else {
+        TRY(enqueue_gpu_job(s, j, then_match));
+        HIPCHK(hipEventRecord(s.ev[10], s.st));
+        HIPCHK(wait_event(s.ev[10]));
+        HIPCHK(wait_event(s.ev[11]));
+    }
     if (s.h_overflow[0]) { set_error("candidate list of a sparse level does not fit the host buffer (raise mcorb_params.cand_cap)"); return MCORB_E_OVERFLOW; }
     const int flags = reinterpret_cast<const int *>(s.h_res)[0];
     if (flags) {
         // the host stage on the same tables (bit 0: a tree below the bucketing depth; bit 1: more than kcap keypoints -- the host
         // stage reports that error itself)
         s.fallbacks++;
+        s.graph_timing = false;
         HIPCHK(hipMemcpyAsync(s.h_tbl, s.d_tbl, (size_t)nimg * s.tbl_ints_per_image * sizeof(int), hipMemcpyDeviceToHost, s.st_copy));
         HIPCHK(hipEventRecord(s.ev[3], s.st_copy));
         return run_select_and_describe(s, j, then_match);
@@ -1142,6 +1189,14 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
     if (then_match && !j.ext_desc)
         for (size_t i = 0; i < s.match_counts.size(); i++) s.match_counts[i] = s.h_nsel[s.match_sets[i]];
     float a = 0, b = 0, c = 0, t = 0;
+    if (graphed) {   // one interval: the whole job
+        for (float &v : s.timing) v = 0.f;
+        (void)hipEventElapsedTime(&a, s.ev_g, s.ev[10]);
+        s.timing[0] = a * 1000.f;
+        s.graph_timing = true;
+        return MCORB_OK;
+    }
+    s.graph_timing = false;
     (void)hipEventElapsedTime(&a, s.ev[0], s.ev[2]);
     (void)hipEventElapsedTime(&b, s.ev[3], s.ev[4]);
     (void)hipEventElapsedTime(&c, s.ev[5], s.ev[6]);
@@ -1370,7 +1425,7 @@ int Rig::finish_match(Slot &s, const Job &j)
     if (j.ext_pairs) pool->parallel_for(s.npairs_done, filter_pair, pool_threads + s.index);   // explicit pairs: lists only, the merge is the caller's
     else if (s.nframes_done > 1) pool->parallel_for(s.nframes_done, one_frame, pool_threads + s.index);
     else if (s.nframes_done == 1) one_frame(0, 0);   // (spreading one frame's pairs over the pool was slower: wake-ups)
-    if (s.npairs_done > 0) {
+    if (s.npairs_done > 0 && !s.graph_timing) {
         float m = 0;
         (void)hipEventElapsedTime(&m, s.ev[7], s.ev[9]); s.timing[3] = m * 1000.f;
         (void)hipEventElapsedTime(&m, s.ev_e, s.ev[8]); s.timing[7] = m * 1000.f;   // k_knn2 (k_expand in front of it: timing[3] - [7] - finalize)

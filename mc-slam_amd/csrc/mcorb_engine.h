@@ -162,6 +162,12 @@ struct Slot {
     size_t res_bytes = 0, res_mono_off = 0, res_resp_off = 0, ctrl_nsel_off = 0;
     int fallbacks = 0;         // jobs of this slot the host stage had to redo (a tree below the bucketing depth)
     hipEvent_t ev_s = nullptr; // k_select + k_assemble finished
+    hipEvent_t ev_g = nullptr; // in front of a replayed job graph
+    struct GraphKey { int nimg, match, nframes, lap0, lap1; float dist_thresh, ratio; };
+    hipGraphExec_t graph_exec = nullptr;   // the captured job (run_gpu_selected), valid for graph_key
+    GraphKey graph_key = {};
+    unsigned job_counter = 0;
+    bool graph_timing = false;             // the last job ran as a graph: timing[] holds the whole job only
     // host, pinned
     uint8_t *h_stage = nullptr, *h_desc = nullptr;
     float *h_angles = nullptr;
@@ -235,6 +241,7 @@ public:
     std::vector<Slot *> slots;
     WorkerPool *pool = nullptr;
     int pool_threads = 0;
+    std::atomic<int> graph_every{0};   // GPU-selected jobs replayed from a captured HIP graph: 0 never, 1 always, K all but every K-th (mcorb_rig_set_graph)
     bool gpu_select = false;   // DistributeOctTree's list discipline runs in k_select (MCORB_SELECT_GPU); else on the worker pool
     int wait_mode = 0;         // how a thread waits for a HIP event: 0 spin (hipEventSynchronize), 1 interrupt-driven, 2 poll + short sleeps
     hipError_t wait_event(hipEvent_t ev) const;
@@ -251,6 +258,7 @@ private:
     int run_extract_phaseA(Slot &s, const Job &j);
     int run_select_and_describe(Slot &s, const Job &j, bool then_match);
     int run_gpu_selected(Slot &s, const Job &j, bool then_match);   // the whole job as one submission (gpu_select)
+    int enqueue_gpu_job(Slot &s, const Job &j, bool then_match);
     int prepare_match(Slot &s, const Job &j);
     int enqueue_match(Slot &s, const Job &j, bool ctrl_on_device);
     int finish_match(Slot &s, const Job &j);

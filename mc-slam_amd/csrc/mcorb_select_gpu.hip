@@ -20,6 +20,7 @@
 // (mono keypoints from the front, stereo ones from the back).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "mcorb_common.h"
@@ -347,11 +348,16 @@ __device__ int careful_round(const SelLds &S, const uint2 *in, int n, uint2 *out
 // grid (images, levels), 64 threads.  out_val[(img * nlevels + level) * selcap + i]: the retained candidates (packed y | x | response)
 // in DistributeOctTree's result order; out_cnt[img * nlevels + level]: how many, or -1 = this level needs the host stage.
 __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom g, uint32_t *__restrict__ out_val, int *__restrict__ out_cnt,
-                                               int selcap, int ldsB, int ldsCap, int *__restrict__ fallback)
+                                               int selcap, int ldsB, int ldsCap, int *__restrict__ fallback, unsigned long long *__restrict__ prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sel_sh[];
     const int lane = sel_lane();
     const int img = blockIdx.x, level = blockIdx.y;
+    int prof_i = 0;
+    auto stamp = [&]() {   // (MCORB_SELECT_PROF: shader-clock stamps of image 0's waves at the phase boundaries)
+        if (prof && img == 0 && lane == 0 && prof_i < 32) prof[level * 32 + prof_i++] = __builtin_amdgcn_s_memtime();
+    };
+    stamp();
     const LevelGeom &L = g.lv[level];
     const int N = L.quota, D = L.depth, B = L.nBuckets, cap = ldsCap;
     const int *tb = tbl + (size_t)img * tbl_ints(g.bucketTotal);
@@ -386,6 +392,7 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom
         for (int b = lane; b < B; b += 64) wdst[b] = wsrc[b];
     }
     sel_sync();
+    stamp();
     // root nodes (:567-600): empty ones are erased
     int n, m = 0, fb = 0, cur = 0;
     {
@@ -407,6 +414,7 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom
     while (!finish) {
         const int prev = n;
         n = full_pass(S, S.list[cur], n, S.list[cur ^ 1], S.exp[0], D, cap, m, fb);
+        stamp();
         if (fb) break;
         cur ^= 1;
         if (n >= N || n == prev) break;
@@ -415,8 +423,10 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom
             while (true) {
                 const int prev2 = n;
                 wave_std_sort(S.exp[ecur], m, S.exp[ecur ^ 1], S);
+                stamp();
                 int m2 = 0;
                 n = careful_round(S, S.list[cur], n, S.list[cur ^ 1], S.exp[ecur ^ 1], m, S.exp[ecur], N, D, cap, m2, fb);
+                stamp();
                 if (fb) break;
                 cur ^= 1;
                 m = m2;
@@ -444,6 +454,7 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom
         oval[i] = bestVal;
     }
     if (lane == 0) *ocnt = n;
+    stamp();
 }
 
 // ORBextractor::operator()'s assembly (:1103-1170), one workgroup per image, one wave per level: levels in order, every level's keypoints in
@@ -548,7 +559,22 @@ hipError_t launch_select(hipStream_t st, const int *tbl, const Geom &g, uint32_t
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    hipLaunchKernelGGL(k_select, dim3(nimg, g.nlevels), dim3(64), lds, st, tbl, g, sel_val, sel_cnt, cap, B, cap, fallback);
+    static unsigned long long *prof = nullptr;
+    static const bool prof_on = getenv("MCORB_SELECT_PROF") != nullptr;
+    if (prof_on && !prof) (void)hipHostMalloc((void **)&prof, kMaxLevels * 32 * 8, hipHostMallocMapped);
+    if (prof_on && prof) {
+        static int calls = 0;
+        if (++calls == 40) {   // a steady-state job: print the previous launch's stamps (cycles between phase boundaries)
+            (void)hipStreamSynchronize(st);
+            for (int l = 0; l < g.nlevels; l++) {
+                fprintf(stderr, "[select prof] level %d:", l);
+                for (int i = 1; i < 32 && prof[l * 32 + i]; i++) fprintf(stderr, " %llu", prof[l * 32 + i] - prof[l * 32 + i - 1]);
+                fprintf(stderr, "\n");
+            }
+        }
+        for (int i = 0; i < kMaxLevels * 32; i++) prof[i] = 0;
+    }
+    hipLaunchKernelGGL(k_select, dim3(nimg, g.nlevels), dim3(64), lds, st, tbl, g, sel_val, sel_cnt, cap, B, cap, fallback, prof_on ? prof : nullptr);
     return hipGetLastError();
 }
 
