@@ -1620,8 +1620,11 @@ __global__ __launch_bounds__(64 * kKnnWaves, kWavesPerSimd) void k_knn2(const ui
                     fold2(u, old[u][4 * s + 2], old[u][4 * s + 3]);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // the ds_read for step g + 2
-                __builtin_amdgcn_sched_group_barrier(0x008, kKnnQT, 0);      // this step's multiplies
-                __builtin_amdgcn_sched_group_barrier(0x002, 5 * kKnnQT, 0);  // four keys' worth of top-2 per query tile
+#pragma unroll
+                for (int u = 0; u < kKnnQT; u++) {                              // a multiply, then five folds (four keys) in its shadow
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+                }
             }
             // (pins the folds in front of the branch below: nothing else uses their results in this block, and the compiler's
             // sinking pass moved all of them behind it, out of the multiplies' shadow)
