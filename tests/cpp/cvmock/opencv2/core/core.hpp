@@ -17,6 +17,9 @@
 #define CV_64F 6
 #define CV_8UC1 CV_8U
 #define CV_Assert(x) assert(x)
+#define CV_VERSION "cvmock (declarations only)"
+
+inline int cvRound(double v) { return (int)std::lrint(v); }   // (global, as in OpenCV; tools/crosscheck only: syntax)
 
 namespace cv {
 
@@ -28,6 +31,11 @@ struct Range {
 struct Point2f {
     float x = 0, y = 0;
 };
+struct Size {
+    int width, height;
+    Size(int w, int h) : width(w), height(h) {}
+};
+enum { INTER_LINEAR = 1, BORDER_REFLECT_101 = 4, NORM_HAMMING = 6 };
 
 struct KeyPoint {   // field order of cv::KeyPoint: pt, size, angle, response, octave, class_id
     Point2f pt;
@@ -42,6 +50,13 @@ public:
     uint8_t *data = nullptr;
     Mat() = default;
     Mat(int r, int c, int type) { create(r, c, type); }
+    Mat(int r, int c, int type, void *ext) : rows(r), cols(c), step((size_t)c), data((uint8_t *)ext), type_(type) {}   // header over caller memory
+    Mat clone() const { Mat m(rows, cols, type_); copyTo(m); return m; }
+    bool isContinuous() const { return step == (size_t)cols * esz(); }
+    uint8_t *ptr(int r) { return data + (size_t)r * step; }
+    const uint8_t *ptr(int r) const { return data + (size_t)r * step; }
+    Mat rowRange(int a, int b) const { return (*this)(Range(a, b), Range(0, cols)); }
+    Mat colRange(int a, int b) const { return (*this)(Range(0, rows), Range(a, b)); }
     void create(int r, int c, int type)
     {
         rows = r; cols = c; type_ = type;

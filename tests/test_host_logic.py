@@ -202,3 +202,18 @@ def test_opencv_flavour_of_the_adapter_is_well_formed():
            "-I" + os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "adapter_opencv_syntax.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_opencv_crosscheck_kit_is_well_formed():
+    """tools/crosscheck/crosscheck_opencv.cpp (the program that would pin the oracle against real OpenCV and the reference's own
+    ORBextractor.cpp) must at least be well-formed C++: -fsyntax-only against tests/cpp/cvmock (declarations, no behaviour) with
+    -DCROSSCHECK_NO_REFERENCE (the reference's header needs the real <opencv2/opencv.hpp>).  Pins nothing, says so itself."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = ["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-DCROSSCHECK_NO_REFERENCE", "-I" + os.path.join(root, "tests", "cpp", "cvmock"),
+           "-I" + os.path.join(root, "include"), "-I" + os.path.join(root, "oracle"), os.path.join(root, "tools", "crosscheck", "crosscheck_opencv.cpp")]
+    out = subprocess.run(cmd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    src = open(os.path.join(root, "tools", "crosscheck", "crosscheck_opencv.cpp")).read()
+    assert "PINS NOTHING UNTIL SOMEONE RUNS IT" in src
