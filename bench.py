@@ -688,9 +688,18 @@ def main():
                     f["mfma_floor_us"] = round(e["mfma_insts_per_launch"] * 32 / SIMDS / CLK_HZ * 1e6, 1)
                 floors[k] = f
     if valu_insts:
-        floor_us = valu_insts * 4 / SIMDS / CLK_HZ * 1e6
-        out["roofline"]["valu"] = {"insts_per_launch": int(valu_insts), "cycles_per_inst": 4, "simds": SIMDS, "clock_ghz": 2.4,
-                                   "floor_us": round(floor_us, 1), "frac_in_flight": round(floor_us / avg_us, 3),
+        # k_fast_cells' issue floor by phase: staging, pass 1 and the work-list expansion are made of the
+        # 4.1-cycle class (packed 16-bit, v_perm, mbcnt: profiles/r03_valu_rates.txt), the arc score + NMS mix sustains 3.0 cycles
+        # per instruction at the kernel's occupancy (the same file's mix_score row); 47 % of a cell-wave's 794 instructions are
+        # score + NMS (245 + 130 of 794)
+        share_score, cyc_a, cyc_b = 0.47, 4.1, 3.0
+        cyc = (1.0 - share_score) * cyc_a + share_score * cyc_b
+        floor_us = valu_insts * cyc / SIMDS / CLK_HZ * 1e6
+        out["roofline"]["valu"] = {"insts_per_launch": int(valu_insts), "cycles_per_inst": round(cyc, 2),
+                                   "cycles_by_phase": {"staging_pass1_expansion": cyc_a, "arc_score_nms": cyc_b, "share_arc_score_nms": share_score},
+                                   "simds": SIMDS, "clock_ghz": 2.4,
+                                   "floor_us": round(floor_us, 1), "floor_us_flat_4_cycles": round(valu_insts * 4 / SIMDS / CLK_HZ * 1e6, 1),
+                                   "frac_in_flight": round(floor_us / avg_us, 3),
                                    "evidence": "profiles/r03_valu_rates.txt (tools/valu_rates.hip, 1/2/4/8 waves per SIMD)"}
     if DIST:
         out["exchange"] = {"collective": "all_gather_into_tensor + gather of the pair tables to rank 0" if PAIRS else "all_to_all_single (uneven splits)", "bytes_sent_per_rank_per_step": int(exchange_bytes * IT), "rounds_per_step": IT,
@@ -753,6 +762,9 @@ def main():
         t1 = t1[1:]
         out["cpu_baseline"] = {"value": round(1.0 / float(np.median(times)), 3), "unit": "frames/s", "cores": NCAMS,
                                "kind": "port", "value_1thread": round(1.0 / float(np.median(t1)), 3),
+                               "note": "the repository's CPU restatement (oracle/), one thread per camera for extraction and ONE matcher thread -- "
+                                       "not the reference's OpenCV build, whose BFMatcher::knnMatch (batchDistance) is parallel_for_-threaded: a reported "
+                                       "baseline that flatters the GPU, never the target (the roofline fractions are)",
                                "sample": "%d rig frames (%s) after 4 warm-ups, CPU oracle, one thread per camera for extraction + "
                                          "matching on the caller thread; median %.1f ms (extract %.1f + match %.1f), p95 %.1f ms; "
                                          "single thread: %d frames, median %.1f ms; host has %d logical cores"

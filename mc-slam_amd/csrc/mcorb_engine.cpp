@@ -762,8 +762,7 @@ int Rig::execute(Slot &s, const Job &j)
     case Job::PROCESS:
         LatProf::mark(0);
         if (gpu_select) {
-            st = run_gpu_selected(s, j, true);
-            LatProf::mark(1); LatProf::mark(2); LatProf::mark(3); LatProf::mark(4); LatProf::mark(5);
+            st = run_gpu_selected(s, j, true);   // (marks 1 .. 5 inside: enqueue | - | - | - | wait GPU | post)
         } else {
             st = run_extract_phaseA(s, j);
             LatProf::mark(1);
@@ -1143,13 +1142,16 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
         HIPCHK(hipEventRecord(s.ev_g, s.st));
         HIPCHK(hipGraphLaunch(s.graph_exec, s.st));
         HIPCHK(hipEventRecord(s.ev[10], s.st));
+        LatProf::mark(1); LatProf::mark(2); LatProf::mark(3); LatProf::mark(4);
         HIPCHK(wait_event(s.ev[10]));
     } else {
         TRY(enqueue_gpu_job(s, j, then_match));
         HIPCHK(hipEventRecord(s.ev[10], s.st));
+        LatProf::mark(1); LatProf::mark(2); LatProf::mark(3); LatProf::mark(4);
         HIPCHK(wait_event(s.ev[10]));
         HIPCHK(wait_event(s.ev[11]));
     }
+    LatProf::mark(5);
     if (s.h_overflow[0]) { set_error("candidate list of a sparse level does not fit the host buffer (raise mcorb_params.cand_cap)"); return MCORB_E_OVERFLOW; }
     const int flags = reinterpret_cast<const int *>(s.h_res)[0];
     if (flags) {
