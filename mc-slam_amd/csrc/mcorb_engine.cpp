@@ -493,6 +493,18 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         s->rig = this;
         s->index = si;
         if (si > 0 && getenv("MCORB_SHARED_STREAM")) { s->st = slots[0]->st; s->shared_st = true; }
+        else if (getenv("MCORB_CU_SPLIT") && atoi(getenv("MCORB_CU_SPLIT")) >= 2) {
+            // experiment: the slots' compute streams are confined to disjoint groups of XCDs (CU-masked
+            // streams), so that jobs of different groups run side by side instead of taking turns on the whole chip
+            const int parts = std::min(8, atoi(getenv("MCORB_CU_SPLIT")));
+            const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+            std::vector<uint32_t> mask(words, 0u);
+            const int part = si % parts;
+            // CU index c belongs to XCD c % 8 in the mask's numbering on this part (round-robin): give a group whole XCDs
+            for (int c = 0; c < ncu; c++)
+                if ((c % 8) * parts / 8 == part) mask[c / 32] |= 1u << (c % 32);
+            HIPCHK(hipExtStreamCreateWithCUMask(&s->st, (uint32_t)words, mask.data()));
+        }
         else HIPCHK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&s->st_copy, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&s->st_dma, hipStreamNonBlocking));

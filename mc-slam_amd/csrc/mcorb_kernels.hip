@@ -1976,7 +1976,10 @@ void launch_fast(hipStream_t st, const uint8_t *pyr, const Geom &g, int iniTh, i
     static const int cap_env = getenv("MCORB_FAST_LISTCAP") ? atoi(getenv("MCORB_FAST_LISTCAP")) : 0;   // tuning knob; any multiple of 8 >= 512 is safe
     const int cap = cap_env >= 512 ? (cap_env & ~7) : kFastListCap;
     const int tileB = (rows * tp + 15) & ~15, scB = ((rows - 4) * tp + 15) & ~15;
-    const size_t lds = 16 + (size_t)tileB + 16 + (size_t)scB + 16 + (size_t)cap * 2;
+    // MCORB_FAST_LDS_PAD (experiment): extra bytes per one-wave workgroup -- 29 waves of 5.4 KiB fill a CU's
+    // 160 KiB, so no other kernel's workgroup fits beside them; padded to 6.6 KiB there are 24 and 32 KiB stay free
+    static const int pad_env = getenv("MCORB_FAST_LDS_PAD") ? atoi(getenv("MCORB_FAST_LDS_PAD")) : 0;
+    const size_t lds = 16 + (size_t)tileB + 16 + (size_t)scB + 16 + (size_t)cap * 2 + (size_t)(pad_env > 0 ? (pad_env & ~15) : 0);
     dim3 grid(g.cells, nimg);
     if (iniTh < 0) iniTh = 0;   // (pass 1's sign tests rely on thresholds in 0 .. 255; FAST thresholds are)
     if (minTh < 0) minTh = 0;
