@@ -1088,7 +1088,7 @@ int Rig::enqueue_gpu_job(Slot &s, const Job &j, bool then_match)
     HIPCHK(hipEventRecord(s.ev[2], s.st));
     launch_compact(s.st, s.d_cellkp, s.d_cellcnt, geom, d_lut, s.d_sorted, s.h_cand, s.d_tbl, s.h_overflow, nimg);
     HIPCHK(hipEventRecord(s.ev_c, s.st));
-    HIPCHK(launch_select(s.st, s.d_tbl, geom, s.d_selval, s.d_selcnt, d_flags, nimg));
+    HIPCHK(launch_select(s.st, s.d_tbl, s.d_sorted, geom, s.d_selval, s.d_selcnt, d_flags, nimg));
     launch_assemble(s.st, s.d_selval, s.d_selcnt, geom, tab.scale, j.lap0, j.lap1, s.d_sel, s.d_res + s.res_resp_off, s.d_nsel,
                     reinterpret_cast<int *>(s.d_res + s.res_mono_off), d_flags, nimg);
     HIPCHK(hipEventRecord(s.ev_s, s.st));

@@ -66,12 +66,12 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
                  int *mcount, hipEvent_t ev_exp, hipEvent_t ev_mid);   // events (optional): after k_expand, after k_knn2
 
 // DistributeOctTree's list discipline + operator()'s assembly on the GPU (mcorb_select_gpu.hip).  tbl: k_compact's device table
-// blocks; sel_val / sel_cnt: select_cap(g) retained candidates and their count per (image, level), -1 = the level needs the host
+// blocks, sorted: its bucket-sorted candidate lists (read only where a tree goes below the bucketing depth); sel_val / sel_cnt: select_cap(g) retained candidates and their count per (image, level), -1 = the level needs the host
 // stage (fallback |= 1); sel / nsel: what the descriptor kernel and the matcher read; resp / mono: FAST responses and monoIndex
 // for the host's keypoint records; fallback bit 1 = more than kcap keypoints.
 int select_cap(const Geom &g);
 bool select_fits(const Geom &g);   // false: the level trees of this geometry do not fit a wave's LDS (very large feature budgets)
-hipError_t launch_select(hipStream_t st, const int *tbl, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg);
+hipError_t launch_select(hipStream_t st, const int *tbl, const uint32_t *sorted, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg);
 void launch_assemble(hipStream_t st, const uint32_t *sel_val, const int *sel_cnt, const Geom &g, const float *scale, int lap0, int lap1,
                      uint32_t *sel, uint8_t *resp, int *nsel, int *mono, int *fallback, int nimg);
 // test hook: std::sort's permutation of n 64-bit entries (upper halves compared) by one wave (wave_std_sort)

@@ -51,29 +51,106 @@ __device__ __forceinline__ int sel_scan3(int v, int &tot)
     return sel_rank(b0) + 2 * sel_rank(b1) + 4 * sel_rank(b2) + v;
 }
 
-// a tree node: x = path code | depth << 24, y = UL.x | UR.x << 16 (level coordinates relative to minX; the y extent is not needed:
-// only UL.x enters compareNodes, and the key sets come from the bucket table)
-__device__ __forceinline__ uint32_t node_code(uint2 n) { return n.x & 0xffffffu; }
-__device__ __forceinline__ int node_depth(uint2 n) { return (int)(n.x >> 24); }
-__device__ __forceinline__ int node_count(const int *bst, uint2 n, int D)
+// a tree node: x = path code (root index, then 2 bits per split) | depth << 28, y = UL.x | UR.x << 16 (level coordinates relative
+// to minX), z = its key count.  Down to the bucketing depth D a node's key set is a run of k_compact's buckets and every count is
+// a difference of bucket starts; a node BELOW D (corners so clustered that fewer than N buckets are non-empty) lives inside one
+// bucket: its key set is that bucket's candidates filtered by the split lines on its path below D, found by scanning the bucket
+// (in device memory) whenever the node is divided or its best key is picked.
+typedef uint4 SelNode;
+constexpr int kSelDepthShift = 28;
+__device__ __forceinline__ uint32_t node_code(SelNode n) { return n.x & ((1u << kSelDepthShift) - 1u); }
+__device__ __forceinline__ int node_depth(SelNode n) { return (int)(n.x >> kSelDepthShift); }
+__device__ __forceinline__ int node_count(SelNode n) { return (int)n.z; }
+
+struct SelCtx {
+    const int *bst;          // bucket starts (LDS)
+    const uint32_t *cand;    // the level's candidates, bucket-sorted (device memory)
+    int D, maxDepth, H0, wCell, hCell;
+    int deepCap;             // a bucket with more candidates than this is not scanned node by node: the level goes to the host stage
+    float hX;
+};
+// geometry of a node below the bucketing depth, recomputed from its path: rectangle (splits happen at its middle) and the
+// split lines below D that bound its key set inside the bucket (a side that no split below D produced is open: root / bucket
+// membership is not a rectangle test -- path_code(), mcorb_common.h)
+struct DeepGeom { int x0, x1, y0, y1, mx0, mx1, my0, my1; };
+__device__ inline DeepGeom deep_geom(const SelCtx &C, SelNode n)
 {
-    const int sh = 2 * (D - node_depth(n));
-    return bst[(node_code(n) + 1) << sh] - bst[node_code(n) << sh];
+    const int d = node_depth(n);
+    const uint32_t code = node_code(n);
+    const int r = (int)(code >> (2 * d));
+    DeepGeom G;
+    G.x0 = (int)__fmul_rn(C.hX, (float)r); G.x1 = (int)__fmul_rn(C.hX, (float)(r + 1));
+    G.y0 = 0; G.y1 = C.H0;
+    G.mx0 = 0; G.mx1 = 1 << 20; G.my0 = 0; G.my1 = 1 << 20;
+    for (int j = 1; j <= d; j++) {
+        const int q = (int)((code >> (2 * (d - j))) & 3u);
+        const int sx = G.x0 + ((G.x1 - G.x0 + 1) >> 1), sy = G.y0 + ((G.y1 - G.y0 + 1) >> 1);
+        if (q & 1) { G.x0 = sx; if (j > C.D) G.mx0 = sx; } else { G.x1 = sx; if (j > C.D) G.mx1 = sx; }
+        if (q & 2) { G.y0 = sy; if (j > C.D) G.my0 = sy; } else { G.y1 = sy; if (j > C.D) G.my1 = sy; }
+    }
+    return G;
 }
-// DivideNode (:479-535) on bucket ranges: key counts of n1..n4
-__device__ __forceinline__ void node_kids(const int *bst, uint2 n, int D, int cnt[4])
+// DivideNode (:479-535): key counts of n1..n4.  Returns false when the node cannot be divided here (path code out of bits, or a
+// bucket too large to scan): the level goes to the host stage.
+__device__ inline bool node_kids(const SelCtx &C, SelNode n, int cnt[4])
 {
-    const int sh = 2 * (D - node_depth(n) - 1);
-    const int base = (int)((node_code(n) << 2) << sh);
-    const int e0 = bst[base], e1 = bst[base + (1 << sh)], e2 = bst[base + (2 << sh)], e3 = bst[base + (3 << sh)], e4 = bst[base + (4 << sh)];
-    cnt[0] = e1 - e0; cnt[1] = e2 - e1; cnt[2] = e3 - e2; cnt[3] = e4 - e3;
+    const int d = node_depth(n);
+    if (d < C.D) {
+        const int sh = 2 * (C.D - d - 1);
+        const int base = (int)((node_code(n) << 2) << sh);
+        const int e0 = C.bst[base], e1 = C.bst[base + (1 << sh)], e2 = C.bst[base + (2 << sh)], e3 = C.bst[base + (3 << sh)], e4 = C.bst[base + (4 << sh)];
+        cnt[0] = e1 - e0; cnt[1] = e2 - e1; cnt[2] = e3 - e2; cnt[3] = e4 - e3;
+        return true;
+    }
+    cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0;
+    if (d >= C.maxDepth) return false;
+    const int b = (int)(node_code(n) >> (2 * (d - C.D)));
+    const int k0 = C.bst[b], k1 = C.bst[b + 1];
+    if (k1 - k0 > C.deepCap) return false;
+    const DeepGeom G = deep_geom(C, n);
+    const int sx = G.x0 + ((G.x1 - G.x0 + 1) >> 1), sy = G.y0 + ((G.y1 - G.y0 + 1) >> 1);
+    for (int k = k0; k < k1; k++) {
+        const uint32_t c = C.cand[k];
+        const int x = cand_x(c), y = cand_y(c);
+        if (x >= G.mx0 && x < G.mx1 && y >= G.my0 && y < G.my1) cnt[(x >= sx ? 1 : 0) + (y >= sy ? 2 : 0)]++;   // (:505-530)
+    }
+    return true;
 }
-__device__ __forceinline__ uint2 node_child(uint2 n, int q)
+__device__ __forceinline__ SelNode node_child(SelNode n, int q, int cnt)
 {
     const int x0 = (int)(n.y & 0xffffu), x1 = (int)(n.y >> 16);
     const int sx = x0 + ((x1 - x0 + 1) >> 1);   // UL.x + ceil((UR.x - UL.x) / 2)
     const int cx0 = (q & 1) ? sx : x0, cx1 = (q & 1) ? x1 : sx;
-    return uint2{((node_code(n) << 2) | (uint32_t)q) | ((uint32_t)(node_depth(n) + 1) << 24), (uint32_t)cx0 | ((uint32_t)cx1 << 16)};
+    return SelNode{((node_code(n) << 2) | (uint32_t)q) | ((uint32_t)(node_depth(n) + 1) << kSelDepthShift), (uint32_t)cx0 | ((uint32_t)cx1 << 16), (uint32_t)cnt, 0u};
+}
+// the node's best key (:757-775): largest response, the first in vToDistributeKeys order among equals (cell row, cell column, y, x)
+__device__ inline uint32_t node_best(const SelCtx &C, const uint2 *win, SelNode n)
+{
+    const int d = node_depth(n);
+    if (d <= C.D) {   // a run of buckets: the best of their winners (k_compact)
+        const int sh = 2 * (C.D - d);
+        const int b0 = (int)(node_code(n) << sh), nb = 1 << sh;
+        uint32_t bestKey = 0, bestVal = 0;
+        for (int b = 0; b < nb; b++) {
+            const uint2 w = win[b0 + b];
+            if (w.x > bestKey) { bestKey = w.x; bestVal = w.y; }
+        }
+        return bestVal;
+    }
+    const int b = (int)(node_code(n) >> (2 * (d - C.D)));
+    const DeepGeom G = deep_geom(C, n);
+    uint32_t best = 0;
+    int bestR = -1;
+    unsigned long long bestO = 0;
+    for (int k = C.bst[b]; k < C.bst[b + 1]; k++) {
+        const uint32_t c = C.cand[k];
+        const int x = cand_x(c), y = cand_y(c), r = cand_resp(c);
+        if (!(x >= G.mx0 && x < G.mx1 && y >= G.my0 && y < G.my1) || r < bestR) continue;
+        const unsigned long long o = (((((unsigned long long)((y - 3) / C.hCell) << 12) | (unsigned long long)((x - 3) / C.wCell)) << 12 | (unsigned long long)y) << 12) |
+                                     (unsigned long long)x;
+        if (r > bestR || o < bestO) { bestR = r; best = c; bestO = o; }
+    }
+    return best;
 }
 // per-node summary of a division: non-empty children (bits 0-3), children with more than one key (bits 4-7), 0x100 = dividable
 __device__ __forceinline__ uint32_t kids_info(const int cnt[4])
@@ -87,14 +164,14 @@ __device__ __forceinline__ uint32_t kids_info(const int cnt[4])
 struct SelLds {
     int *bst;                 // bucket starts of this level (B + 1)
     const uint2 *win;         // the buckets' winners {key, candidate} (k_compact), staged while the tree is built
-    uint2 *list[2];           // node lists, ping-pong
+    SelNode *list[2];         // node lists, ping-pong
     uint64_t *exp[2];         // (key count << 12 | UL.x) << 32 | list position of the nodes that can still be divided
     uint16_t *ta, *tb;        // scratch: partition positions (sort) / per-node and per-entry division summaries (passes)
     uint32_t *blk;            // sort: block of every position (first | last << 16)
     int *stk;                 // sort: range stack
 };
 constexpr int kSelStack = 3 * 48;
-__host__ __device__ inline size_t sel_lds_bytes(int B, int cap) { return (size_t)(B + 1 + 3) / 4 * 16 + (size_t)(B + 1) / 2 * 16 + (size_t)cap * (2 * 8 + 2 * 8 + 2 * 2 + 4) + kSelStack * 4; }
+__host__ __device__ inline size_t sel_lds_bytes(int B, int cap) { return (size_t)(B + 1 + 3) / 4 * 16 + (size_t)(B + 1) / 2 * 16 + (size_t)cap * (2 * 16 + 2 * 8 + 2 * 2 + 4) + kSelStack * 4; }
 
 // std::sort(a, a + n) on the upper halves, libstdc++'s permutation (mcorb_sortmodel.h); the result is in `out`
 __device__ void wave_std_sort(uint64_t *a, int n, uint64_t *out, SelLds &S)
@@ -183,10 +260,9 @@ __device__ void wave_std_sort(uint64_t *a, int n, uint64_t *out, SelLds &S)
 }
 
 // one full pass over the list (:615-678); returns the new length, m = nodes that can be divided again (nToExpand)
-__device__ int full_pass(const SelLds &S, const uint2 *in, int n, uint2 *out, uint64_t *exp, int D, int cap, int &m, int &fb)
+__device__ int full_pass(const SelLds &S, const SelCtx &C, const SelNode *in, int n, SelNode *out, uint64_t *exp, int cap, int &m, int &fb)
 {
     const int lane = sel_lane();
-    const int *bst = S.bst;
     uint16_t *info = S.ta;
     int H = 0, bad = 0, singles = 0;
     for (int c0 = 0; c0 < n; c0 += 64) {
@@ -194,16 +270,13 @@ __device__ int full_pass(const SelLds &S, const uint2 *in, int n, uint2 *out, ui
         int nc = 0;
         uint32_t inf = 0x100u;
         if (i < n) {
-            const uint2 nd = in[i];
+            const SelNode nd = in[i];
             inf = 0;
-            if (node_count(bst, nd, D) > 1) {
-                if (node_depth(nd) >= D) bad = 1;   // would have to split a bucket: needs the candidates themselves
-                else {
-                    int cnt[4];
-                    node_kids(bst, nd, D, cnt);
-                    inf = kids_info(cnt);
-                    nc = __popc(inf & 15u);
-                }
+            if (node_count(nd) > 1) {
+                int cnt[4];
+                if (!node_kids(C, nd, cnt)) bad = 1;
+                inf = kids_info(cnt);
+                nc = __popc(inf & 15u);
             }
             info[i] = (uint16_t)inf;
         }
@@ -225,14 +298,14 @@ __device__ int full_pass(const SelLds &S, const uint2 *in, int n, uint2 *out, ui
         const bool single = i < n && !(inf & 0x100u);
         const unsigned long long bs = __ballot(single);
         if (inf & 0x100u) {
-            const uint2 nd = in[i];
+            const SelNode nd = in[i];
             int cnt[4];
-            node_kids(bst, nd, D, cnt);
+            (void)node_kids(C, nd, cnt);
             const int cincl = crun + cin, eexcl = erun + ein - ne;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (!((mask >> q) & 1u)) continue;
-                const uint2 ch = node_child(nd, q);
+                const SelNode ch = node_child(nd, q, cnt[q]);
                 const int pos = H - cincl + __popc(mask >> (q + 1));   // children pushed later (q' > q) sit further to the front
                 out[pos] = ch;
                 if ((emask >> q) & 1u)
@@ -251,29 +324,25 @@ __device__ int full_pass(const SelLds &S, const uint2 *in, int n, uint2 *out, ui
 }
 
 // one round of the careful phase (:688-752): `srt` = the dividable nodes sorted by std::sort; divides from the back until N nodes
-__device__ int careful_round(const SelLds &S, const uint2 *in, int n, uint2 *out, const uint64_t *srt, int m, uint64_t *exp, int N, int D, int cap,
+__device__ int careful_round(const SelLds &S, const SelCtx &C, const SelNode *in, int n, SelNode *out, const uint64_t *srt, int m, uint64_t *exp, int N, int cap,
                              int &mOut, int &fb)
 {
     const int lane = sel_lane();
-    const int *bst = S.bst;
     uint16_t *divided = S.ta, *einfo = S.tb;   // per old list position: divided in this round; per entry (division order): summary
     for (int i = lane; i < n; i += 64) divided[i] = 0;
     // division order t = 0 .. m-1 is the sorted order from the back; k = how many divisions until the list holds N nodes
-    int k = -1, srun = 0, bad = 0;
+    int k = -1, srun = 0;
     for (int t0 = 0; t0 < m && k < 0; t0 += 64) {
         const int t = t0 + lane;
         int inc = 0;
         if (t < m) {
-            const uint2 nd = in[(uint32_t)srt[m - 1 - t]];
-            uint32_t inf = 0x100u;
-            if (node_depth(nd) >= D) bad = 1;
-            else {
-                int cnt[4];
-                node_kids(bst, nd, D, cnt);
-                inf = kids_info(cnt);
-            }
+            const SelNode nd = in[(uint32_t)srt[m - 1 - t]];
+            int cnt[4];
+            const bool ok = node_kids(C, nd, cnt);
+            const uint32_t inf = kids_info(cnt) | (ok ? 0u : 0x200u);   // 0x200: cannot be divided here
             einfo[t] = (uint16_t)inf;
             inc = __popc(inf & 15u);
+            if (!ok) inc = 1;   // (counts as "no change"; if it is among the divided ones the level goes to the host)
         }
         int itot;
         const int sin = sel_scan3(inc, itot) - (lane + 1);   // a division replaces one node by its non-empty children
@@ -283,24 +352,16 @@ __device__ int careful_round(const SelLds &S, const uint2 *in, int n, uint2 *out
     }
     if (k < 0) k = m;
     sel_sync();
-    // (a node at the bucketing depth among the ones that really get divided: the host has to do this level)
-    int Hc = 0;
+    int Hc = 0, badk = 0;
     for (int t0 = 0; t0 < k; t0 += 64) {
         const int t = t0 + lane;
         const uint32_t inf = t < k ? einfo[t] : 0u;
+        if (inf & 0x200u) badk = 1;
         int tot;
         (void)sel_scan3(__popc(inf & 15u), tot);
         Hc += tot;
     }
-    {
-        int badk = 0;
-        for (int t0 = 0; t0 < k; t0 += 64) {
-            const int t = t0 + lane;
-            if (t < k && node_depth(in[(uint32_t)srt[m - 1 - t]]) >= D) badk = 1;
-        }
-        (void)bad;
-        if (__ballot(badk != 0) != 0ull || Hc + n - k > cap) { fb = 1; mOut = 0; return n; }
-    }
+    if (__ballot(badk != 0) != 0ull || Hc + n - k > cap) { fb = 1; mOut = 0; return n; }
     int crun = 0, erun = 0;
     for (int t0 = 0; t0 < k; t0 += 64) {
         const int t = t0 + lane;
@@ -311,15 +372,15 @@ __device__ int careful_round(const SelLds &S, const uint2 *in, int n, uint2 *out
         const int cin = sel_scan3(nc, ctot), ein = sel_scan3(ne, etot);
         if (t < k) {
             const uint32_t pos0 = (uint32_t)srt[m - 1 - t];
-            const uint2 nd = in[pos0];
+            const SelNode nd = in[pos0];
             divided[pos0] = 1;
             int cnt[4];
-            node_kids(bst, nd, D, cnt);
+            (void)node_kids(C, nd, cnt);
             const int cincl = crun + cin, eexcl = erun + ein - ne;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (!((mask >> q) & 1u)) continue;
-                const uint2 ch = node_child(nd, q);
+                const SelNode ch = node_child(nd, q, cnt[q]);
                 const int pos = Hc - cincl + __popc(mask >> (q + 1));
                 out[pos] = ch;
                 if ((emask >> q) & 1u)
@@ -347,8 +408,8 @@ __device__ int careful_round(const SelLds &S, const uint2 *in, int n, uint2 *out
 
 // grid (images, levels), 64 threads.  out_val[(img * nlevels + level) * selcap + i]: the retained candidates (packed y | x | response)
 // in DistributeOctTree's result order; out_cnt[img * nlevels + level]: how many, or -1 = this level needs the host stage.
-__global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom g, uint32_t *__restrict__ out_val, int *__restrict__ out_cnt,
-                                               int selcap, int ldsB, int ldsCap, int *__restrict__ fallback, unsigned long long *__restrict__ prof)
+__global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, const uint32_t *__restrict__ sorted, Geom g, uint32_t *__restrict__ out_val, int *__restrict__ out_cnt,
+                                               int selcap, int ldsB, int ldsCap, int deepCap, int *__restrict__ fallback, unsigned long long *__restrict__ prof)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t sel_sh[];
     const int lane = sel_lane();
@@ -373,8 +434,8 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom
         uint8_t *p = sel_sh;
         S.bst = reinterpret_cast<int *>(p); p += (size_t)(ldsB + 1 + 3) / 4 * 16;
         S.win = reinterpret_cast<const uint2 *>(p); p += (size_t)(ldsB + 1) / 2 * 16;
-        S.list[0] = reinterpret_cast<uint2 *>(p); p += (size_t)cap * 8;
-        S.list[1] = reinterpret_cast<uint2 *>(p); p += (size_t)cap * 8;
+        S.list[0] = reinterpret_cast<SelNode *>(p); p += (size_t)cap * 16;
+        S.list[1] = reinterpret_cast<SelNode *>(p); p += (size_t)cap * 16;
         S.exp[0] = reinterpret_cast<uint64_t *>(p); p += (size_t)cap * 8;
         S.exp[1] = reinterpret_cast<uint64_t *>(p); p += (size_t)cap * 8;
         S.blk = reinterpret_cast<uint32_t *>(p); p += (size_t)cap * 4;
@@ -382,6 +443,20 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom
         S.tb = reinterpret_cast<uint16_t *>(p); p += (size_t)cap * 2;
         S.stk = reinterpret_cast<int *>(p);
     }
+    SelCtx C;
+    C.bst = S.bst;
+    C.cand = sorted + (size_t)img * g.candCap + tb[kTblLvlOff + level];
+    C.D = D;
+    {   // path codes keep the root index above 2 bits per split, in 28 bits
+        int rootBits = 0;
+        while ((1 << rootBits) < L.nIni) rootBits++;
+        C.maxDepth = min(14, (kSelDepthShift - rootBits) / 2);
+    }
+    C.H0 = L.maxBorderY - kMinBorder;
+    C.wCell = L.wCell > 0 ? L.wCell : (1 << 20);
+    C.hCell = L.hCell > 0 ? L.hCell : (1 << 20);
+    C.hX = L.hX;
+    C.deepCap = deepCap;
     // the level's bucket starts and bucket winners: global -> LDS, all loads in flight at once (the winners are not needed before
     // the tree is finished)
     {
@@ -398,22 +473,23 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom
     {
         const int i = lane;
         bool keep = false;
-        uint2 nd{0, 0};
+        SelNode nd{0, 0, 0, 0};
         if (i < L.nIni) {
             nd.x = (uint32_t)i;
             nd.y = (uint32_t)(int)__fmul_rn(L.hX, (float)i) | ((uint32_t)(int)__fmul_rn(L.hX, (float)(i + 1)) << 16);
-            keep = node_count(S.bst, nd, D) > 0;
+            nd.z = (uint32_t)(S.bst[(i + 1) << (2 * D)] - S.bst[i << (2 * D)]);
+            keep = nd.z > 0;
         }
         const unsigned long long b = __ballot(keep);
         if (keep) S.list[0][sel_rank(b)] = nd;
         n = __popcll(b);
     }
     sel_sync();
-    if (L.nIni > 64 || L.nIni < 1 || N + 8 > cap) fb = 1;
+    if (L.nIni > 64 || L.nIni < 1 || N + 8 > cap || C.maxDepth < D) fb = 1;
     bool finish = fb != 0;
     while (!finish) {
         const int prev = n;
-        n = full_pass(S, S.list[cur], n, S.list[cur ^ 1], S.exp[0], D, cap, m, fb);
+        n = full_pass(S, C, S.list[cur], n, S.list[cur ^ 1], S.exp[0], cap, m, fb);
         stamp();
         if (fb) break;
         cur ^= 1;
@@ -425,7 +501,7 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom
                 wave_std_sort(S.exp[ecur], m, S.exp[ecur ^ 1], S);
                 stamp();
                 int m2 = 0;
-                n = careful_round(S, S.list[cur], n, S.list[cur ^ 1], S.exp[ecur ^ 1], m, S.exp[ecur], N, D, cap, m2, fb);
+                n = careful_round(S, C, S.list[cur], n, S.list[cur ^ 1], S.exp[ecur ^ 1], m, S.exp[ecur], N, cap, m2, fb);
                 stamp();
                 if (fb) break;
                 cur ^= 1;
@@ -439,20 +515,9 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, Geom
         if (lane == 0) { *ocnt = -1; atomicOr(fallback, 1); }
         return;
     }
-    // best response per node (:757-775) = the best of its buckets' winners (k_compact)
-    const uint2 *win = S.win;
-    const uint2 *list = S.list[cur];
-    for (int i = lane; i < n; i += 64) {
-        const uint2 nd = list[i];
-        const int sh = 2 * (D - node_depth(nd));
-        const int b0 = (int)(node_code(nd) << sh), nb = 1 << sh;
-        uint32_t bestKey = 0, bestVal = 0;
-        for (int b = 0; b < nb; b++) {
-            const uint2 w = win[b0 + b];
-            if (w.x > bestKey) { bestKey = w.x; bestVal = w.y; }
-        }
-        oval[i] = bestVal;
-    }
+    // best response per node (:757-775)
+    const SelNode *list = S.list[cur];
+    for (int i = lane; i < n; i += 64) oval[i] = node_best(C, S.win, list[i]);
     if (lane == 0) *ocnt = n;
     stamp();
 }
@@ -547,7 +612,7 @@ bool select_fits(const Geom &g)
     return select_cap(g) <= 65535 && select_lds(g, B) <= 160 * 1024;
 }
 
-hipError_t launch_select(hipStream_t st, const int *tbl, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg)
+hipError_t launch_select(hipStream_t st, const int *tbl, const uint32_t *sorted, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg)
 {
     int B;
     const int cap = select_cap(g);
@@ -559,6 +624,8 @@ hipError_t launch_select(hipStream_t st, const int *tbl, const Geom &g, uint32_t
         if (e != hipSuccess) return e;
         configured = lds;
     }
+    // (MCORB_SELECT_DEEP_CAP: test knob -- a small value sends clustered levels to the host stage)
+    const int deep_cap = getenv("MCORB_SELECT_DEEP_CAP") ? atoi(getenv("MCORB_SELECT_DEEP_CAP")) : 4096;
     static unsigned long long *prof = nullptr;
     static const bool prof_on = getenv("MCORB_SELECT_PROF") != nullptr;
     if (prof_on && !prof) (void)hipHostMalloc((void **)&prof, kMaxLevels * 32 * 8, hipHostMallocMapped);
@@ -574,7 +641,7 @@ hipError_t launch_select(hipStream_t st, const int *tbl, const Geom &g, uint32_t
         }
         for (int i = 0; i < kMaxLevels * 32; i++) prof[i] = 0;
     }
-    hipLaunchKernelGGL(k_select, dim3(nimg, g.nlevels), dim3(64), lds, st, tbl, g, sel_val, sel_cnt, cap, B, cap, fallback, prof_on ? prof : nullptr);
+    hipLaunchKernelGGL(k_select, dim3(nimg, g.nlevels), dim3(64), lds, st, tbl, sorted, g, sel_val, sel_cnt, cap, B, cap, deep_cap, fallback, prof_on ? prof : nullptr);
     return hipGetLastError();
 }
 

@@ -99,16 +99,25 @@ def test_gpu_selected_job_equals_host_selected_job_and_oracle(mc, W, H, C, N):
         r.close()
 
 
-def test_clustered_corners_fall_back_to_the_host_stage(mc):
-    """corners only inside forty small patches: fewer non-empty buckets than the level's quota, so the tree has to divide nodes at
-    the bucketing depth -- k_select raises the flag, the batch is redone through the host stage, and the result is the oracle's"""
-    W, H = 800, 600
-    rng = np.random.default_rng(42)
+def _clustered_image(W, H, seed=42, patches=40):
+    rng = np.random.default_rng(seed)
     base = np.full((H, W), 128, np.int64)
-    for _ in range(40):
+    for _ in range(patches):
         x, y = int(rng.integers(30, W - 60)), int(rng.integers(30, H - 60))
         base[y:y + 24, x:x + 24] = rng.integers(0, 256, (24, 24))
-    img = base.astype(np.uint8)
+    return base.astype(np.uint8)
+
+
+@pytest.mark.parametrize("deep_cap,fallbacks", [(None, 0), ("8", 1)])
+def test_clustered_corners_below_the_bucketing_depth(mc, monkeypatch, deep_cap, fallbacks):
+    """corners only inside forty small patches: fewer non-empty buckets than the level's quota, so the tree divides nodes BELOW the
+    bucketing depth.  k_select does that itself (the bucket's candidates filtered by the split lines of the node's path); with the
+    scan cap turned down to 8 candidates (test knob) it raises the flag instead and the batch is redone through the host stage.
+    Either way the result is the oracle's."""
+    if deep_cap:
+        monkeypatch.setenv("MCORB_SELECT_DEEP_CAP", deep_cap)
+    W, H = 800, 600
+    img = _clustered_image(W, H)
     rig = mc.Rig(1, W, H, 1, 1, nfeatures=1000, selection=2)
     rig.upload([img])
     rig.extract(1)
@@ -118,7 +127,28 @@ def test_clustered_corners_fall_back_to_the_host_stage(mc):
     for fld in ref[1].dtype.names:
         assert np.array_equal(ref[1][fld], k2[fld]), fld
     assert np.array_equal(ref[2], d2)
-    assert rig.select_fallbacks() == 1
+    assert rig.select_fallbacks() == fallbacks
+    rig.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_deep_trees_on_the_gpu_random_clusters(mc, seed):
+    """more clustered layouts (few / many patches, different sizes and budgets): no level may need the host stage, and the
+    keypoints are the oracle's"""
+    rng = np.random.default_rng(100 + seed)
+    W, H = int(rng.integers(500, 1100)), int(rng.integers(400, 700))
+    img = _clustered_image(W, H, seed=seed, patches=int(rng.integers(3, 60)))
+    nf = int(rng.integers(300, 2000))
+    rig = mc.Rig(1, W, H, 1, 1, nfeatures=nf, selection=2)
+    rig.upload([img])
+    rig.extract(1)
+    ref = O.OracleExtractor(nf)(img)
+    m2, k2, d2 = rig.features(0)
+    assert ref[0] == m2 and len(ref[1]) == len(k2)
+    for fld in ref[1].dtype.names:
+        assert np.array_equal(ref[1][fld], k2[fld]), fld
+    assert np.array_equal(ref[2], d2)
+    assert rig.select_fallbacks() == 0
     rig.close()
 
 
