@@ -198,7 +198,35 @@ __device__ void wave_std_sort(uint64_t *a, int n, uint64_t *out, SelLds &S)
             const int mi = sm_median3(ka, kb, kc, f + 1, mid, l - 1);
             if (lane == 0) { const uint64_t t = a[f]; a[f] = a[mi]; a[mi] = t; }
             sel_sync();
-            const uint32_t p = sm_key(a[f]);
+            const uint32_t p = mi == f + 1 ? ka : (mi == mid ? kb : kc);   // = key(a[f]) after the swap
+            if (l - f - 1 <= 64) {
+                // the range fits the wave: one position per lane, one read; lane j learns L_j (ascending) and R_j (descending)
+                // through the crossbar (ds_permute: an L lane sends its position to lane #(L lanes below it), the others to the
+                // unused lanes behind), and the cut comes out of registers -- a third of the LDS round trips of the general path
+                const int i = f + 1 + lane;
+                const bool in = i < l;
+                const uint32_t k = sm_key(a[min(i, l - 1)]);
+                const bool isL = in && !(k < p), isR = in && !(p < k);
+                const unsigned long long bl = __ballot(isL), br = __ballot(isR);
+                const int nL = __popcll(bl), nR = __popcll(br);
+                const int below = sel_rank(bl);                                            // L lanes below this one
+                const int above = __popcll(lane == 63 ? 0ull : br >> (lane + 1));          // R lanes above this one
+                const int Lj = __builtin_amdgcn_ds_permute((isL ? below : nL + (lane - below)) << 2, i);
+                const int Rj = __builtin_amdgcn_ds_permute((isR ? above : nR + (63 - lane - above)) << 2, i);
+                const bool ok = lane < min(nL, nR) && Lj < Rj;
+                const int s = __popcll(__ballot(ok));   // (a prefix of the lanes: L ascends, R descends)
+                const int nextL = s < nL ? __builtin_amdgcn_readlane(Lj, s) : (1 << 30), lastR = s > 0 ? __builtin_amdgcn_readlane(Rj, s - 1) : (1 << 30);
+                const int cut = min(nextL, lastR);
+                if (lane < s) {
+                    const uint64_t ex = a[Lj], ey = a[Rj];
+                    a[Lj] = ey; a[Rj] = ex;
+                }
+                if (lane == 0) { S.stk[3 * sp] = cut; S.stk[3 * sp + 1] = l; S.stk[3 * sp + 2] = dl; }
+                sp++;
+                l = cut;
+                sel_sync();
+                continue;
+            }
             // L: positions of (f, l) with key >= p, ascending; R: positions with key <= p, descending
             int nL = 0, nR = 0;
             for (int c0 = f + 1; c0 < l; c0 += 64) {
