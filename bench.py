@@ -285,6 +285,9 @@ def main():
     rig = mcorb.Rig(NCAMS, W, H, max_frames=fps, nslots=S, nfeatures=NFEAT, device_id=local)
     if args.graph is not None:
         rig.set_graph(args.graph)
+    if rig.select_mode() == "gpu":   # the selection's time slot holds k_select + k_assemble (HIP events), not the host stage's wall time
+        TIMING_FIELD.pop("select_host", None)
+        TIMING_FIELD["k_select+k_assemble"] = "select_us"
     kcap = rig.kcap
     total_frames = F * N               # rig frames per exchange round over all ranks (N = 1: per step)
 

@@ -476,6 +476,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         if (mode == MCORB_SELECT_AUTO && e) mode = !strcmp(e, "host") ? MCORB_SELECT_HOST : (!strcmp(e, "gpu") ? MCORB_SELECT_GPU : MCORB_SELECT_AUTO);
         if (mode != MCORB_SELECT_AUTO && mode != MCORB_SELECT_HOST && mode != MCORB_SELECT_GPU) { set_error("mcorb_params.selection: unknown mode"); return MCORB_E_ARG; }
         gpu_select = mode != MCORB_SELECT_HOST && select_fits(geom);
+        // (test knob, read once here -- never from the slot drivers' threads: a getenv per launch raced with a profiler's setenv)
+        if (getenv("MCORB_SELECT_DEEP_CAP")) select_deep_cap = std::max(1, atoi(getenv("MCORB_SELECT_DEEP_CAP")));
         // HIP graphs: a single-slot rig (one job at a time, how MC-SLAM calls) replays its job from a captured graph -- 0.41 -> 0.35 ms
         // per rig frame; with several jobs in flight the replay measured 3 - 5 % SLOWER than launch by launch (profiles/r04_graph.txt)
         graph_every = !gpu_select ? 0 : getenv("MCORB_GRAPH") ? std::max(0, atoi(getenv("MCORB_GRAPH"))) : (nslots == 1 ? 1 : 0);   // (mcorb_rig_select_mode reports what the rig really runs)
@@ -1088,7 +1090,7 @@ int Rig::enqueue_gpu_job(Slot &s, const Job &j, bool then_match)
     HIPCHK(hipEventRecord(s.ev[2], s.st));
     launch_compact(s.st, s.d_cellkp, s.d_cellcnt, geom, d_lut, s.d_sorted, s.h_cand, s.d_tbl, s.h_overflow, nimg);
     HIPCHK(hipEventRecord(s.ev_c, s.st));
-    HIPCHK(launch_select(s.st, s.d_tbl, s.d_sorted, geom, s.d_selval, s.d_selcnt, d_flags, nimg));
+    HIPCHK(launch_select(s.st, s.d_tbl, s.d_sorted, geom, s.d_selval, s.d_selcnt, d_flags, nimg, select_deep_cap));
     launch_assemble(s.st, s.d_selval, s.d_selcnt, geom, tab.scale, j.lap0, j.lap1, s.d_sel, s.d_res + s.res_resp_off, s.d_nsel,
                     reinterpret_cast<int *>(s.d_res + s.res_mono_off), d_flags, nimg);
     HIPCHK(hipEventRecord(s.ev_s, s.st));

@@ -242,6 +242,7 @@ public:
     WorkerPool *pool = nullptr;
     int pool_threads = 0;
     std::atomic<int> graph_every{0};   // GPU-selected jobs replayed from a captured HIP graph: 0 never, 1 always, K all but every K-th (mcorb_rig_set_graph)
+    int select_deep_cap = 4096; // k_select: largest bucket it scans node by node below the bucketing depth (MCORB_SELECT_DEEP_CAP at rig creation)
     bool gpu_select = false;   // DistributeOctTree's list discipline runs in k_select (MCORB_SELECT_GPU); else on the worker pool
     int wait_mode = 0;         // how a thread waits for a HIP event: 0 spin (hipEventSynchronize), 1 interrupt-driven, 2 poll + short sleeps
     hipError_t wait_event(hipEvent_t ev) const;

@@ -71,7 +71,8 @@ void launch_knn2(hipStream_t st, const uint8_t *desc, const int *counts, const i
 // for the host's keypoint records; fallback bit 1 = more than kcap keypoints.
 int select_cap(const Geom &g);
 bool select_fits(const Geom &g);   // false: the level trees of this geometry do not fit a wave's LDS (very large feature budgets)
-hipError_t launch_select(hipStream_t st, const int *tbl, const uint32_t *sorted, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg);
+// deep_cap: a bucket with more candidates than this is not scanned node by node when a tree goes below the bucketing depth
+hipError_t launch_select(hipStream_t st, const int *tbl, const uint32_t *sorted, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg, int deep_cap = 4096);
 void launch_assemble(hipStream_t st, const uint32_t *sel_val, const int *sel_cnt, const Geom &g, const float *scale, int lap0, int lap1,
                      uint32_t *sel, uint8_t *resp, int *nsel, int *mono, int *fallback, int nimg);
 // test hook: std::sort's permutation of n 64-bit entries (upper halves compared) by one wave (wave_std_sort)

@@ -1196,7 +1196,11 @@ __global__ __launch_bounds__(256) void k_describe(const uint8_t *__restrict__ bl
 // ---------------------------------------------------------------------------
 constexpr int kFdSrcDw = 34 * 12 + 4;    // + one chunk of slack: the (unused) 28th column of the last row reads past it
 constexpr int kFdPairs = 17, kFdHpPitch = 28, kFdHpDw = kFdPairs * kFdHpPitch;
-constexpr int kFdOutPitchDw = 8, kFdOutDw = 28 * kFdOutPitchDw;
+constexpr int kFdOutPitchDw = 7, kFdOutDw = 28 * kFdOutPitchDw;   // 28-byte rows: with 32 the tap reads hit the same bank more often (tools/gen_brief_groups.py)
+// which descriptor byte (8 consecutive test pairs) the octet g of tap round j compares: slot 8 j + g (brief_groups_31.inc)
+__constant__ uint8_t c_brief_groups[64] = {   // [0, 32): slot -> byte; [32, 64): byte -> slot
+#include "brief_groups_31.inc"
+};
 constexpr int kFdWaveDw = kFdSrcDw + kFdHpDw + kFdOutDw;
 
 template <int B>
@@ -1276,14 +1280,19 @@ __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restric
         toff[q] = row | (ch << 8);
         tlds[q] = row * 12 + 4 * ch;
     }
-    // this lane's four test pairs (pairs lane, 64+lane, 128+lane, 192+lane) as byte offsets into `out`
+    // this lane's four test pairs as byte offsets into `out`.  Round j, octet g = lane / 8 compares descriptor byte
+    // c_brief_groups[8 j + g] (pairs 8 b + lane % 8): the bytes are dealt to the rounds and half-waves so that the 32 lanes of a
+    // half hit few LDS banks twice -- 32 instead of 54 LDS cycles for a keypoint's eight ds_read_u8 (the pattern is constant:
+    // tools/gen_brief_groups.py).  A ballot word still holds eight whole descriptor bytes, only their order differs.
     int o0[4], o1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int p = (j * 64 + lane) * 4;
+        const int p = (8 * (int)c_brief_groups[8 * j + (lane >> 3)] + (lane & 7)) * 4;
         o0[j] = (c_pattern[p + 1] + 13) * (kFdOutPitchDw * 4) + c_pattern[p] + 13;
         o1[j] = (c_pattern[p + 3] + 13) * (kFdOutPitchDw * 4) + c_pattern[p + 2] + 13;
     }
+    // where descriptor byte (lane % 32) ends up: ballot word bslot >> 3, byte bslot & 7
+    const int bslot = c_brief_groups[32 + (lane & 31)];
 
     // window fetch of keypoint u into (va, vb); kept in plain scalars (an array captured by a lambda ended up in scratch)
     uint4 va, vb;
@@ -1358,11 +1367,18 @@ __global__ __launch_bounds__(256) void k_describe_fused(const uint8_t *__restric
         unsigned long long bits[4];
 #pragma unroll
         for (int j = 0; j < 4; j++) bits[j] = __ballot(c[o0[j]] < c[o1[j]]);
-        if (lane < 4 && k0 + u < n) {
+        // the four ballot words hold the 32 descriptor bytes in slot order: through 32 bytes of LDS (the row-pair region is idle
+        // by now), lane b picks up descriptor byte b from its slot
+        if (lane < 4) {
             const unsigned long long b = lane == 0 ? bits[0] : lane == 1 ? bits[1] : lane == 2 ? bits[2] : bits[3];
-            reinterpret_cast<unsigned long long *>(desc + ((size_t)img * g.kcap + k0 + u) * 32)[lane] = b;
+            reinterpret_cast<unsigned long long *>(hp)[lane] = b;
+        }
+        fd_wave_sync();
+        if (lane < 32 && k0 + u < n) {   // lane b stores descriptor byte b
+            const uint8_t byte = reinterpret_cast<const uint8_t *>(hp)[bslot];
+            desc[((size_t)img * g.kcap + k0 + u) * 32 + lane] = byte;
             // small batches: the host's copy is written here too (host-mapped memory) instead of by a copy behind the kernel
-            if (desc_host) reinterpret_cast<unsigned long long *>(desc_host + ((size_t)img * g.kcap + k0 + u) * 32)[lane] = b;
+            if (desc_host) desc_host[((size_t)img * g.kcap + k0 + u) * 32 + lane] = byte;
         }
     }
 #undef FD_FETCH

@@ -640,7 +640,7 @@ bool select_fits(const Geom &g)
     return select_cap(g) <= 65535 && select_lds(g, B) <= 160 * 1024;
 }
 
-hipError_t launch_select(hipStream_t st, const int *tbl, const uint32_t *sorted, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg)
+hipError_t launch_select(hipStream_t st, const int *tbl, const uint32_t *sorted, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg, int deep_cap)
 {
     int B;
     const int cap = select_cap(g);
@@ -652,8 +652,6 @@ hipError_t launch_select(hipStream_t st, const int *tbl, const uint32_t *sorted,
         if (e != hipSuccess) return e;
         configured = lds;
     }
-    // (MCORB_SELECT_DEEP_CAP: test knob -- a small value sends clustered levels to the host stage)
-    const int deep_cap = getenv("MCORB_SELECT_DEEP_CAP") ? atoi(getenv("MCORB_SELECT_DEEP_CAP")) : 4096;
     static unsigned long long *prof = nullptr;
     static const bool prof_on = getenv("MCORB_SELECT_PROF") != nullptr;
     if (prof_on && !prof) (void)hipHostMalloc((void **)&prof, kMaxLevels * 32 * 8, hipHostMallocMapped);

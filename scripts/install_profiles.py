@@ -18,7 +18,8 @@ for a, b in [("bench_default.json", "bench_default.json"), ("stats_default.csv",
              ("stats_1slot.csv", "stats_1slot_kernel_stats.csv"), ("fetch.txt", "pmc_fetch_size_summary.txt"),
              ("write.txt", "pmc_write_size_summary.txt"), ("sq.txt", "pmc_sq_counters.txt"), ("calib.txt", "fetch_calibration.txt"),
              ("bow_rate.json", "bow_rate.json"), ("lf_rate.json", "lf_rate.json"), ("n1_rate.json", "n1_rate.json"),
-             ("latency.json", "latency.json"), ("valu_rates.txt", "valu_rates.txt")]:
+             ("latency.json", "latency.json"), ("latency_nograph.json", "latency_nograph.json"), ("latency_hostselect.json", "latency_hostselect.json"),
+             ("fp4_probe.txt", "fp4_probe.txt"), ("valu_rates.txt", "valu_rates.txt")]:
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(P, "%s_%s" % (tag, b)))
 
