@@ -40,7 +40,9 @@ CONFIGS = {
     "1080p8": dict(W=1920, H=1080, NCAMS=8, NFEAT=2000,
                    label="8-cam rig 1920x1080, 2000 kpts/cam, extract + all-pairs intra-rig match (configs[2])"),
 }
-IMAGES_PER_LAUNCH = 128     # camera images per slot job (32 four-camera or 16 eight-camera rig frames)
+IMAGES_PER_LAUNCH = 512     # camera images per slot job (128 four-camera or 64 eight-camera rig frames): with the selection on the GPU the
+                            # job has a latency-bound middle (k_compact, k_select, k_assemble: ~90 us whatever the batch) that larger
+                            # batches amortise -- 128 images x 5 slots 37.5 k, 256 x 4 39.1 k, 512 x 4 40.0 k (profiles/r04_overlap.txt)
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is what a copy achieves
 GPU_KERNELS = ("k_resize", "k_fast_cells", "k_compact", "k_describe_fused", "k_knn2")   # k_blur: only with MCORB_BLUR_PLANES / orientation
 TIMING_FIELD = {"k_resize": "pyramid_us", "k_fast_cells": "fast_us", "k_compact": "compact_us",
@@ -267,15 +269,18 @@ def main():
         raise SystemExit("supported combinations: --exchange a2a --partition frames (default), --exchange allgather --partition pairs")
     if PAIRS:
         os.environ.setdefault("MCORB_BENCH_GROUPS", "1")   # the literal 8(e) path is run round by round, not pipelined
-    # jobs in flight: with the selection on the GPU a job is one submission and five are enough (six measured 3 - 8 % slower:
-    # profiles/r04_slots.txt); the host selection needs a sixth to hide its round trip
-    S = args.slots if args.slots else ((2 if PAIRS else 12) if DIST else (6 if os.environ.get("MCORB_SELECT") == "host" else 5))
+    # jobs in flight: with the selection on the GPU a job is one submission and four (of 512 images) are enough (profiles/r04_overlap.txt);
+    # the host selection needs more to hide its round trip
+    S = args.slots if args.slots else ((2 if PAIRS else 12) if DIST else (6 if os.environ.get("MCORB_SELECT") == "host" else 4))
     G = int(os.environ.get("MCORB_BENCH_GROUPS", "6")) if DIST else 1   # slot groups: with N > 1 G-1 groups extract ahead while one is matched
     IT = 2 if DIST else 1              # exchange rounds per step on the N > 1 path (one round = one group = SG slot jobs per rank)
     if DIST and S % G:
         S += G - S % G
     SG = S // G                        # slots per group
-    F = args.frames if args.frames else SG * max(1, IMAGES_PER_LAUNCH // NCAMS)
+    # (the larger batch pays on the fused single-GPU path of the 720p rig only: the sharded pipeline and the 1080p rig measured
+    # 5 - 8 % slower with it -- 35.9 vs 37.9 k, 8.1 vs 8.8 k -- and keep 128 images per job)
+    ipl = IMAGES_PER_LAUNCH if (not DIST and args.config == "720p4") else 128
+    F = args.frames if args.frames else SG * max(1, ipl // NCAMS)
     S = max(1, min(S, F)) if not DIST else S
     fps = F // SG                      # rig frames per slot job
     if fps * SG != F:
@@ -633,7 +638,10 @@ def main():
             else:
                 traffic = int(tj[dominant]["bytes_per_image"] * nimg_launch)
                 traffic_note = tj.get("_correction", "")
+                # (the counters were read on launches of tj[...]["images_per_launch"] images: scaled to this run's launch size)
+                lscale = nimg_launch / float(tj[dominant].get("images_per_launch", nimg_launch))
                 valu_insts = tj[dominant].get("valu_insts_per_launch")
+                valu_insts = valu_insts * lscale if valu_insts else valu_insts
         except Exception as e:      # noqa: BLE001
             traffic_note = "profiles/traffic.json unreadable: %s" % e
     out = {
@@ -685,10 +693,11 @@ def main():
         for k in GPU_KERNELS:
             e = tj.get(k, {})
             if e.get("valu_insts_per_launch"):
-                f = {"valu_insts": int(e["valu_insts_per_launch"]), "valu_floor_us": round(e["valu_insts_per_launch"] * 4 / SIMDS / CLK_HZ * 1e6, 1)}
+                sc = nimg_launch / float(e.get("images_per_launch", nimg_launch))   # counters of a 128-image launch -> this launch size
+                f = {"valu_insts": int(e["valu_insts_per_launch"] * sc), "valu_floor_us": round(e["valu_insts_per_launch"] * sc * 4 / SIMDS / CLK_HZ * 1e6, 1)}
                 if e.get("mfma_insts_per_launch"):
-                    f["mfma_insts"] = int(e["mfma_insts_per_launch"])
-                    f["mfma_floor_us"] = round(e["mfma_insts_per_launch"] * 32 / SIMDS / CLK_HZ * 1e6, 1)
+                    f["mfma_insts"] = int(e["mfma_insts_per_launch"] * sc)
+                    f["mfma_floor_us"] = round(e["mfma_insts_per_launch"] * sc * 32.6 / SIMDS / CLK_HZ * 1e6, 1)   # 32.6 cycles per scaled FP4 step (r04_fp4_probe.txt)
                 floors[k] = f
     if valu_insts:
         # k_fast_cells' issue floor by phase: staging, pass 1 and the work-list expansion are made of the
