@@ -35,7 +35,7 @@ def kib(path):
 
 
 bench = json.load(open(os.path.join(P, tag + "_bench_default.json")))
-NIMG = bench["roofline"]["images_per_launch"]   # the one-slot runs use the same launch size
+NIMG = 128   # the counter runs of scripts/collect_profiles.sh launch 32 four-camera rig frames (--slots 1 --frames 32), whatever the bench line's batch is
 f, w = kib(os.path.join(P, tag + "_pmc_fetch_size_summary.txt")), kib(os.path.join(P, tag + "_pmc_write_size_summary.txt"))
 sha = hashlib.sha256(open(os.path.join(ROOT, "mc-slam_amd", "csrc", "mcorb_kernels.hip"), "rb").read()).hexdigest()[:16]
 out = {"_source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
