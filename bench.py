@@ -806,7 +806,9 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         from latency import measure
         lat = measure(mcorb, NCAMS, W, H, NFEAT, frames=100)
-        out["single_frame_latency_ms"] = {k: lat[k] for k in ("upload_ms", "extract_match_ms", "readback_ms", "total_ms", "total_p95_ms")}
+        out["single_frame_latency_ms"] = {k: lat[k] for k in ("upload_ms", "extract_match_ms", "readback_ms", "total_ms", "total_p95_ms", "separated")}
+        out["single_frame_latency_ms"]["note"] = ("upload_ms = staging copy + DMA enqueue; the PCIe transfer itself runs at the head of "
+                                                  "extract_match_ms (`separated` drains the stream between the two)")
     if N == 1 and not DIST and not args.no_extra_legs and args.config == "720p4":
         # two more driver-visible numbers, each from a fresh child process after this one's legs are done (its rig is closed):
         rig.close()

@@ -480,6 +480,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         if (getenv("MCORB_SELECT_DEEP_CAP")) select_deep_cap = std::max(1, atoi(getenv("MCORB_SELECT_DEEP_CAP")));
         // HIP graphs: a single-slot rig (one job at a time, how MC-SLAM calls) replays its job from a captured graph -- 0.41 -> 0.35 ms
         // per rig frame; with several jobs in flight the replay measured 3 - 5 % SLOWER than launch by launch (profiles/r04_graph.txt)
+        upload_pipelined = !(getenv("MCORB_UPLOAD_PIPE") && atoi(getenv("MCORB_UPLOAD_PIPE")) == 0);   // (A/B knob)
         graph_every = !gpu_select ? 0 : getenv("MCORB_GRAPH") ? std::max(0, atoi(getenv("MCORB_GRAPH"))) : (nslots == 1 ? 1 : 0);   // (mcorb_rig_select_mode reports what the rig really runs)
     }
     pool = new WorkerPool(nthreads);
@@ -572,6 +573,7 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
             TRY(dev_alloc(&s->d_res, s->res_bytes));
             TRY(host_alloc(&s->h_res, s->res_bytes));
             HIPCHK(hipMemset(s->d_res, 0, s->res_bytes));
+            TRY(host_alloc(&s->h_sig, M));
             HIPCHK(hipEventCreateWithFlags(&s->ev_s, hipEventDefault));
             HIPCHK(hipEventCreateWithFlags(&s->ev_g, hipEventDefault));
         }
@@ -616,7 +618,7 @@ Rig::~Rig()
         (void)hipFree(s->d_knn); (void)hipHostFree(s->h_mlist); (void)hipHostFree(s->h_mcount); (void)hipHostFree(s->h_ctrl); (void)hipFree(s->d_ctrl);
         (void)hipHostFree(s->h_stage);
         (void)hipHostFree(s->h_desc); (void)hipHostFree(s->h_angles);
-        (void)hipFree(s->d_selval); (void)hipFree(s->d_selcnt); (void)hipFree(s->d_res); (void)hipHostFree(s->h_res);
+        (void)hipFree(s->d_selval); (void)hipFree(s->d_selcnt); (void)hipFree(s->d_res); (void)hipHostFree(s->h_res); (void)hipHostFree(s->h_sig);
         if (s->ev_s) (void)hipEventDestroy(s->ev_s);
         if (s->ev_g) (void)hipEventDestroy(s->ev_g);
         if (s->graph_exec) (void)hipGraphExecDestroy(s->graph_exec);
@@ -668,6 +670,29 @@ int Rig::upload_u8(int slot, const uint8_t *const *images, int nimg, int stride)
         if (stride == W) memcpy(dst, images[m], (size_t)W * H);
         else for (int y = 0; y < H; y++) memcpy(dst + (size_t)y * W, images[m] + (size_t)y * stride, W);
     };
+    if (nimg > 1 && nimg <= kSmallBatch && upload_pipelined) {
+        // one rig frame at a time: the staging copy and the DMA overlap -- the planes are copied a quarter at a time, image by image,
+        // and whoever finishes an image's last quarter puts its DMA on the stream while the others go on with the next image
+        constexpr int Q = 4;
+        std::atomic<int> left[kSmallBatch];
+        for (int m = 0; m < nimg; m++) left[m].store(Q);
+        std::atomic<int> err{(int)hipSuccess};
+        const size_t plane = (size_t)W * H;
+        auto quarter = [&](int t, int) {
+            const int m = t / Q, q = t % Q, y0 = H * q / Q, y1 = H * (q + 1) / Q;
+            uint8_t *dst = s.h_stage + (size_t)m * plane;
+            if (stride == W) memcpy(dst + (size_t)y0 * W, images[m] + (size_t)y0 * W, (size_t)(y1 - y0) * W);
+            else for (int y = y0; y < y1; y++) memcpy(dst + (size_t)y * W, images[m] + (size_t)y * stride, W);
+            if (left[m].fetch_sub(1, std::memory_order_acq_rel) != 1) return;
+            hipError_t e = hipSetDevice(device);   // (pool threads make no other HIP call)
+            if (e == hipSuccess)
+                e = hipMemcpy2DAsync(s.d_pyr + (size_t)m * geom.imgBytes + geom.lv[0].off, geom.lv[0].pitch, dst, W, W, H, hipMemcpyHostToDevice, s.st);
+            if (e != hipSuccess) err.store((int)e);
+        };
+        pool->parallel_for(nimg * Q, quarter, pool_threads + s.index);
+        HIPCHK((hipError_t)err.load());
+        return MCORB_OK;
+    }
     if (nimg > 1) pool->parallel_for(nimg, copy_one, pool_threads + s.index);
     else copy_one(0, 0);
     return upload_staged(slot, nimg);
@@ -756,9 +781,10 @@ static void flush()
 {
     if (!on) return;
     for (int i = 1; i < 9; i++) acc[i] += t[i] - t[i - 1];
+    acc[9] += t[9] - t[6]; acc[10] += t[10] - t[9];   // inside finish_match: accept lists unpacked | tracks merged
     if (++n % 50 == 0) {
-        fprintf(stderr, "[mcorb lat prof] per job: enqueue A %.0f us, wait tables %.0f, select %.0f, prepare+enqueue B %.0f, wait GPU %.0f, post %.0f, merge %.0f, total %.0f\n",
-                acc[1] / 50, acc[2] / 50, acc[3] / 50, acc[4] / 50, acc[5] / 50, acc[6] / 50, acc[7] / 50, (acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6] + acc[7]) / 50);
+        fprintf(stderr, "[mcorb lat prof] per job: enqueue A %.0f us, wait tables %.0f, select %.0f, prepare+enqueue B %.0f, wait GPU %.0f, post %.0f, merge %.0f (lists %.0f, tracks %.0f), total %.0f\n",
+                acc[1] / 50, acc[2] / 50, acc[3] / 50, acc[4] / 50, acc[5] / 50, acc[6] / 50, acc[7] / 50, acc[9] / 50, acc[10] / 50, (acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6] + acc[7]) / 50);
         for (int i = 0; i < 12; i++) acc[i] = 0;
     }
 }
@@ -1079,27 +1105,46 @@ int Rig::enqueue_gpu_job(Slot &s, const Job &j, bool then_match)
 {
     const int nimg = j.nimg;
     (void)hipGetLastError();   // (a stale error of this thread -- e.g. an elapsed-time query on an event a replayed graph never recorded -- is not this job's)
-    if (then_match)   // pair list / set map first: k_assemble overwrites the control block's nsel and sel afterwards, in stream order
+    // A small batch (one rig frame at a time) is launch- and copy-bound: its results travel through host-mapped memory -- k_assemble
+    // writes the host's sel / responses / counts itself and signals them per image, k_describe_fused writes the host's descriptors, the
+    // matcher reads its pair list from the host's control block: no copy is left in the job.
+    const bool small = s.gpu_small;
+    if (then_match && !small)   // pair list / set map first: k_assemble overwrites the control block's nsel and sel afterwards, in stream order
         HIPCHK(hipMemcpyAsync(s.d_ctrl, s.h_ctrl, s.ctrl_pairs_end, hipMemcpyHostToDevice, s.st));
     int *d_flags = reinterpret_cast<int *>(s.d_res);
-    HIPCHK(hipMemsetAsync(d_flags, 0, 16 * sizeof(int), s.st));
-    HIPCHK(hipEventRecord(s.ev[0], s.st));
+    if (!small) HIPCHK(hipMemsetAsync(d_flags, 0, 16 * sizeof(int), s.st));   // (a small batch's flags travel with its per-image signals)
+    // (a small batch replayed from its graph: kernels only -- event-record nodes between them split the graph into separately
+    // submitted pieces, and nothing reads these events after a replay)
+    const bool ev_on = !(small && s.capturing);
+    if (ev_on) HIPCHK(hipEventRecord(s.ev[0], s.st));
     launch_pyramid(s.st, s.d_pyr, geom, d_taps, resize_win, nimg);
-    HIPCHK(hipEventRecord(s.ev[1], s.st));
+    if (ev_on) HIPCHK(hipEventRecord(s.ev[1], s.st));
     launch_fast(s.st, s.d_pyr, geom, params.ini_th_fast, params.min_th_fast, d_fasttab + fast_cell_off, s.d_cellkp, s.d_cellcnt, nimg);
-    HIPCHK(hipEventRecord(s.ev[2], s.st));
+    if (ev_on) HIPCHK(hipEventRecord(s.ev[2], s.st));
     launch_compact(s.st, s.d_cellkp, s.d_cellcnt, geom, d_lut, s.d_sorted, s.h_cand, s.d_tbl, s.h_overflow, nimg);
-    HIPCHK(hipEventRecord(s.ev_c, s.st));
+    if (ev_on) HIPCHK(hipEventRecord(s.ev_c, s.st));
     HIPCHK(launch_select(s.st, s.d_tbl, s.d_sorted, geom, s.d_selval, s.d_selcnt, d_flags, nimg, select_deep_cap));
-    launch_assemble(s.st, s.d_selval, s.d_selcnt, geom, tab.scale, j.lap0, j.lap1, s.d_sel, s.d_res + s.res_resp_off, s.d_nsel,
-                    reinterpret_cast<int *>(s.d_res + s.res_mono_off), d_flags, nimg);
-    HIPCHK(hipEventRecord(s.ev_s, s.st));
-    HIPCHK(hipEventRecord(s.ev[3], s.st));
+    if (small)
+        launch_assemble(s.st, s.d_selval, s.d_selcnt, geom, tab.scale, j.lap0, j.lap1, s.d_sel, s.d_res + s.res_resp_off, s.d_nsel,
+                        reinterpret_cast<int *>(s.d_res + s.res_mono_off), d_flags, nimg, s.h_sel, s.h_res + s.res_resp_off, s.h_nsel,
+                        reinterpret_cast<int *>(s.h_res + s.res_mono_off), s.h_sig);
+    else
+        launch_assemble(s.st, s.d_selval, s.d_selcnt, geom, tab.scale, j.lap0, j.lap1, s.d_sel, s.d_res + s.res_resp_off, s.d_nsel,
+                        reinterpret_cast<int *>(s.d_res + s.res_mono_off), d_flags, nimg);
+    if (ev_on) HIPCHK(hipEventRecord(s.ev_s, s.st));
+    if (ev_on) HIPCHK(hipEventRecord(s.ev[3], s.st));
     if (blur_planes) launch_blur(s.st, s.d_pyr, s.d_blur, geom, nimg);
-    HIPCHK(hipEventRecord(s.ev[4], s.st));
-    HIPCHK(hipEventRecord(s.ev[5], s.st));
-    launch_describe(s.st, s.d_pyr, blur_planes ? s.d_blur : nullptr, geom, s.d_sel, s.d_nsel, params.orientation, s.d_desc, s.d_angles, nimg);
-    HIPCHK(hipEventRecord(s.ev[6], s.st));
+    if (ev_on) HIPCHK(hipEventRecord(s.ev[4], s.st));
+    if (ev_on) HIPCHK(hipEventRecord(s.ev[5], s.st));
+    launch_describe(s.st, s.d_pyr, blur_planes ? s.d_blur : nullptr, geom, s.d_sel, s.d_nsel, params.orientation, s.d_desc, s.d_angles, nimg,
+                    small ? s.h_desc : nullptr);
+    if (ev_on) HIPCHK(hipEventRecord(s.ev[6], s.st));
+    if (small) {
+        if (then_match) TRY(enqueue_match(s, j, true));
+        HIPCHK(hipGetLastError());
+        if (ev_on) HIPCHK(hipEventRecord(s.ev[11], s.st));
+        return MCORB_OK;
+    }
     // results to the host on the side stream while the matcher runs: descriptors, the control block from nsel on (nsel, the set
     // map and pair list as uploaded, sel), responses + monoIndex + flags
     HIPCHK(hipStreamWaitEvent(s.st_dma, s.ev[6], 0));
@@ -1128,64 +1173,23 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
     s.small_job = false;
     s.h_overflow[0] = 0;
     s.nimg_done = nimg;
+    s.gpu_small = nimg <= kSmallBatch && params.orientation == 0 && !blur_planes && !j.ext_desc;
     if (then_match) TRY(prepare_match(s, j));
+    if (s.gpu_small)
+        for (int m = 0; m < nimg; m++) reinterpret_cast<volatile int *>(s.h_sig)[m] = 0;
     s.blur_valid = blur_planes;
     // The job is the same ~20 launches and copies every time: captured once per (slot, shape of the job) into a HIP graph and
     // replayed with one call -- the CPU side of a job drops from ~20 runtime calls to one, the gaps between its kernels shrink.
     // (Per-kernel HIP events do not exist inside a replayed graph: mcorb_rig_last_timing reports the job as a whole then.)
     // graph_every: 0 = never, 1 = every job, K > 1 = all but every K-th job of a slot, which runs launch by launch with its
     // per-kernel events (a sample of the same pipeline for mcorb_rig_last_timing)
-    const int ge = graph_every.load(std::memory_order_relaxed);
-    const bool graphed = ge > 0 && !j.ext_desc && (ge == 1 || (++s.job_counter % ge) != 0);
-    if (graphed) {
-        const Slot::GraphKey key{nimg, then_match ? 1 : 0, j.nframes, j.lap0, j.lap1, j.dist_thresh, j.ratio};
-        if (!s.graph_exec || memcmp(&key, &s.graph_key, sizeof(key)) != 0) {
-            if (s.graph_exec) { (void)hipGraphExecDestroy(s.graph_exec); s.graph_exec = nullptr; }
-            hipGraph_t graph = nullptr;
-            HIPCHK(hipStreamBeginCapture(s.st, hipStreamCaptureModeThreadLocal));
-            int st = enqueue_gpu_job(s, j, then_match);
-            hipError_t e = hipStreamWaitEvent(s.st, s.ev[11], 0);   // the side stream joins again
-            const hipError_t e2 = hipStreamEndCapture(s.st, &graph);
-            if (st != MCORB_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
-            if (e == hipSuccess) e = e2;
-            if (e == hipSuccess) e = hipGraphInstantiate(&s.graph_exec, graph, nullptr, nullptr, 0);
-            if (graph) (void)hipGraphDestroy(graph);
-            if (e != hipSuccess) { s.graph_exec = nullptr; set_error(std::string("graph capture: ") + hipGetErrorString(e)); return MCORB_E_HIP; }
-            s.graph_key = key;
-        }
-        HIPCHK(hipEventRecord(s.ev_g, s.st));
-        HIPCHK(hipGraphLaunch(s.graph_exec, s.st));
-        HIPCHK(hipEventRecord(s.ev[10], s.st));
-        LatProf::mark(1); LatProf::mark(2); LatProf::mark(3); LatProf::mark(4);
-        HIPCHK(wait_event(s.ev[10]));
-    } else {
-        TRY(enqueue_gpu_job(s, j, then_match));
-        HIPCHK(hipEventRecord(s.ev[10], s.st));
-        LatProf::mark(1); LatProf::mark(2); LatProf::mark(3); LatProf::mark(4);
-        HIPCHK(wait_event(s.ev[10]));
-        HIPCHK(wait_event(s.ev[11]));
-    }
-    LatProf::mark(5);
-    if (s.h_overflow[0]) { set_error("candidate list of a sparse level does not fit the host buffer (raise mcorb_params.cand_cap)"); return MCORB_E_OVERFLOW; }
-    const int flags = reinterpret_cast<const int *>(s.h_res)[0];
-    if (flags) {
-        // the host stage on the same tables (bit 0: a tree below the bucketing depth; bit 1: more than kcap keypoints -- the host
-        // stage reports that error itself)
-        s.fallbacks++;
-        s.graph_timing = false;
-        HIPCHK(hipMemcpyAsync(s.h_tbl, s.d_tbl, (size_t)nimg * s.tbl_ints_per_image * sizeof(int), hipMemcpyDeviceToHost, s.st_copy));
-        HIPCHK(hipEventRecord(s.ev[3], s.st_copy));
-        return run_select_and_describe(s, j, then_match);
-    }
-    // keypoint records (ORBextractor.cpp:1103-1170's fields) from what k_assemble left: one pool task per image
-    const int *mono = reinterpret_cast<const int *>(s.h_res + s.res_mono_off);
-    const uint8_t *resp = s.h_res + s.res_resp_off;
-    pool->parallel_for(nimg, [&](int m, int) {
+    // keypoint records (ORBextractor.cpp:1103-1170's fields) of one image from what k_assemble left
+    auto records = [&](int m) {
         const int n = s.h_nsel[m];
         std::vector<mcorb_keypoint> &K = s.kps[m];
         K.resize((size_t)n);
         const uint32_t *sel = s.h_sel + (size_t)m * geom.kcap;
-        const uint8_t *rs = resp + (size_t)m * geom.kcap;
+        const uint8_t *rs = s.h_res + s.res_resp_off + (size_t)m * geom.kcap;
         const float *ang = params.orientation ? s.h_angles + (size_t)m * geom.kcap : nullptr;
         for (int k = 0; k < n; k++) {
             const uint32_t v = sel[k];
@@ -1200,8 +1204,82 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
             if (l != 0) { kp.x *= tab.scale[l]; kp.y *= tab.scale[l]; }
             K[k] = kp;
         }
-        s.mono[m] = mono[m];
-    }, pool_threads + s.index);
+        s.mono[m] = reinterpret_cast<const int *>(s.h_res + s.res_mono_off)[m];
+    };
+    // a small batch: the records are built here, image by image as k_assemble signals them, while the descriptor and matching
+    // kernels still run; returns the number of images done (all of them unless the job ended without signalling: an error), -1 on
+    // a HIP error
+    int records_done = 0, small_flags = 0;
+    auto records_early = [&](hipEvent_t end) {
+        const volatile int *sig = s.h_sig;
+        for (int m = 0; m < nimg; m++) {
+            unsigned spins = 0;
+            while (!sig[m]) {
+                if ((++spins & (wait_mode == 2 ? 0u : 1023u)) == 0) {
+                    const hipError_t e = hipEventQuery(end);
+                    if (e == hipSuccess) { if (!sig[m]) return; break; }   // the job is over: nothing more will be signalled
+                    if (e != hipErrorNotReady) { set_error(std::string("event query: ") + hipGetErrorString(e)); records_done = -1; return; }
+                }
+                if (wait_mode == 2) { timespec ts = {0, 20000}; nanosleep(&ts, nullptr); }   // (slot drivers that poll: no core per slot)
+                else __builtin_ia32_pause();
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (sig[m] & 0x100) small_flags |= sig[m] & 3;
+            records(m);
+            records_done = m + 1;
+        }
+    };
+    const int ge = graph_every.load(std::memory_order_relaxed);
+    const bool graphed = ge > 0 && !j.ext_desc && (ge == 1 || (++s.job_counter % ge) != 0);
+    if (graphed) {
+        const Slot::GraphKey key{nimg, then_match ? 1 : 0, j.nframes, j.lap0, j.lap1, j.dist_thresh, j.ratio};
+        if (!s.graph_exec || memcmp(&key, &s.graph_key, sizeof(key)) != 0) {
+            if (s.graph_exec) { (void)hipGraphExecDestroy(s.graph_exec); s.graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIPCHK(hipStreamBeginCapture(s.st, hipStreamCaptureModeThreadLocal));
+            s.capturing = true;
+            int st = enqueue_gpu_job(s, j, then_match);
+            s.capturing = false;
+            hipError_t e = s.gpu_small ? hipSuccess : hipStreamWaitEvent(s.st, s.ev[11], 0);   // the side stream joins again
+            const hipError_t e2 = hipStreamEndCapture(s.st, &graph);
+            if (st != MCORB_OK) { if (graph) (void)hipGraphDestroy(graph); return st; }
+            if (e == hipSuccess) e = e2;
+            if (e == hipSuccess) e = hipGraphInstantiate(&s.graph_exec, graph, nullptr, nullptr, 0);
+            if (graph) (void)hipGraphDestroy(graph);
+            if (e != hipSuccess) { s.graph_exec = nullptr; set_error(std::string("graph capture: ") + hipGetErrorString(e)); return MCORB_E_HIP; }
+            s.graph_key = key;
+        }
+        HIPCHK(hipEventRecord(s.ev_g, s.st));
+        HIPCHK(hipGraphLaunch(s.graph_exec, s.st));
+        HIPCHK(hipEventRecord(s.ev[10], s.st));
+        LatProf::mark(1); LatProf::mark(2); LatProf::mark(3);
+        if (s.gpu_small) records_early(s.ev[10]);
+        LatProf::mark(4);
+        HIPCHK(wait_event(s.ev[10]));
+    } else {
+        TRY(enqueue_gpu_job(s, j, then_match));
+        HIPCHK(hipEventRecord(s.ev[10], s.st));
+        LatProf::mark(1); LatProf::mark(2); LatProf::mark(3);
+        if (s.gpu_small) records_early(s.ev[10]);
+        LatProf::mark(4);
+        HIPCHK(wait_event(s.ev[10]));
+        HIPCHK(wait_event(s.ev[11]));
+    }
+    LatProf::mark(5);
+    if (s.h_overflow[0]) { set_error("candidate list of a sparse level does not fit the host buffer (raise mcorb_params.cand_cap)"); return MCORB_E_OVERFLOW; }
+    if (records_done < 0) return MCORB_E_HIP;
+    if (s.gpu_small && records_done < nimg) { set_error("extract: the job ended without its results"); return MCORB_E_HIP; }
+    const int flags = s.gpu_small ? small_flags : reinterpret_cast<const int *>(s.h_res)[0];
+    if (flags) {
+        // the host stage on the same tables (bit 0: a tree below the bucketing depth; bit 1: more than kcap keypoints -- the host
+        // stage reports that error itself)
+        s.fallbacks++;
+        s.graph_timing = false;
+        HIPCHK(hipMemcpyAsync(s.h_tbl, s.d_tbl, (size_t)nimg * s.tbl_ints_per_image * sizeof(int), hipMemcpyDeviceToHost, s.st_copy));
+        HIPCHK(hipEventRecord(s.ev[3], s.st_copy));
+        return run_select_and_describe(s, j, then_match);
+    }
+    if (records_done < nimg) pool->parallel_for(nimg, [&](int m, int) { records(m); }, pool_threads + s.index);
     if (then_match && !j.ext_desc)
         for (size_t i = 0; i < s.match_counts.size(); i++) s.match_counts[i] = s.h_nsel[s.match_sets[i]];
     float a = 0, b = 0, c = 0, t = 0;
@@ -1314,12 +1392,13 @@ int Rig::enqueue_match(Slot &s, const Job &j, bool ctrl_on_device)
     }
     if (s.npairs_done == 0) return MCORB_OK;
     const bool ext = j.ext_desc != nullptr;
-    HIPCHK(hipEventRecord(s.ev[7], s.st));
-    const bool hostctrl = ctrl_on_device && s.small_job && !ext;   // (the fused path of a small batch: no H2D copy was made)
-    launch_knn2(s.st, ext ? (const uint8_t *)j.ext_desc : s.d_desc, ext ? s.d_extcounts : (hostctrl ? s.h_nsel : s.d_nsel),
+    const bool ev_on = !(s.gpu_small && s.capturing);   // (see enqueue_gpu_job)
+    if (ev_on) HIPCHK(hipEventRecord(s.ev[7], s.st));
+    const bool hostctrl = ctrl_on_device && (s.small_job || s.gpu_small) && !ext;   // (the fused path of a small batch: no H2D copy was made)
+    launch_knn2(s.st, ext ? (const uint8_t *)j.ext_desc : s.d_desc, ext ? s.d_extcounts : (hostctrl && !s.gpu_small ? s.h_nsel : s.d_nsel),
                 hostctrl ? s.h_setmap : s.d_setmap, s.nsets_local, hostctrl ? s.h_pairs : s.d_pairs, s.npairs_done, geom.kcap, s.d_exp, s.d_lcounts, s.d_part, j.dist_thresh, j.ratio, s.d_knn, s.h_mlist,
-                s.h_mcount, s.ev_e, s.ev[8]);
-    HIPCHK(hipEventRecord(s.ev[9], s.st));
+                s.h_mcount, ev_on ? s.ev_e : nullptr, ev_on ? s.ev[8] : nullptr);
+    if (ev_on) HIPCHK(hipEventRecord(s.ev[9], s.st));
     HIPCHK(hipGetLastError());
     return MCORB_OK;
 }
@@ -1360,8 +1439,9 @@ void merge_pair_lists(int C, const int *counts, const uint32_t *const *idx1, con
         size_t o = 0;
         for (int c = 0; c < C; c++) { inv[c] = inv_flat.data() + o; o += (size_t)std::max(counts[c], 0); }
         for (int p = 0; p < C * (C - 1) / 2; p++) worst += (size_t)std::max(np[p], 0);
-        tr.reserve(worst * C);   // a track per accepted match at most
+        tr.resize(worst * C);   // a track per accepted match at most; cut to the tracks made at the end
     }
+    int32_t *T = tr.data();
     int pl = 0;
     for (int a = 0; a < C - 1; a++) {
         for (int b = a + 1; b < C; b++, pl++) {
@@ -1371,16 +1451,17 @@ void merge_pair_lists(int C, const int *counts, const uint32_t *const *idx1, con
                 const int ma = inv[a][fa], mb = inv[b][fb];
                 if (gate && !epipolar_ok(gate->F + 9 * pl, gate->kps[a][fa], gate->kps[b][fb], gate->sigma2)) continue;
                 if (ma == -1 && mb == -1) {
-                    tr.resize((size_t)(ntr + 1) * C, -1);
-                    tr[(size_t)ntr * C + a] = fa;
-                    tr[(size_t)ntr * C + b] = fb;
+                    int32_t *row = T + (size_t)ntr * C;
+                    for (int c = 0; c < C; c++) row[c] = -1;
+                    row[a] = fa;
+                    row[b] = fb;
                     inv[a][fa] = ntr;
                     inv[b][fb] = ntr;
                     ntr++;
                 } else {
                     if (ma == -1 && mb != -1) {
-                        if (tr[(size_t)mb * C + a] == -1) {
-                            tr[(size_t)mb * C + a] = fa;
+                        if (T[(size_t)mb * C + a] == -1) {
+                            T[(size_t)mb * C + a] = fa;
                             inv[a][fa] = mb;
                         }
                     }
@@ -1388,13 +1469,14 @@ void merge_pair_lists(int C, const int *counts, const uint32_t *const *idx1, con
                         if (ma != mb) mergeable++;
                     }
                     if (ma != -1 && mb == -1) {
-                        tr[(size_t)ma * C + b] = fb;
+                        T[(size_t)ma * C + b] = fb;
                         inv[b][fb] = ma;
                     }
                 }
             }
         }
     }
+    tr.resize((size_t)ntr * C);
     mergeable_out = mergeable;
 }
 
@@ -1434,8 +1516,24 @@ int Rig::finish_match(Slot &s, const Job &j)
             for (int e = 0; e < cnt[b]; e++, k++) { i1[k] = ml[b * kKnnQueriesPerBlock + e] >> 16; i2[k] = ml[b * kKnnQueriesPerBlock + e] & 0xffffu; }
     };
     auto one_frame = [&](int f, int w) {
+        // the accept lists were written by the GPU into pinned host memory: every line is a miss, and the lists are short runs
+        // (one per 256 queries) that the hardware prefetcher does not get ahead of -- ask for all of a frame's lines at once
+        {
+            const int nqb = knn_qblocks(geom.kcap);
+            for (int pi = f * npp; pi < (f + 1) * npp; pi++) {
+                const int *cnt = s.h_mcount + (size_t)pi * nqb;
+                const uint32_t *ml = s.h_mlist + (size_t)pi * knn_mlist_stride(geom.kcap);
+                for (int b = 0; b < nqb; b++) {
+                    const char *p0 = reinterpret_cast<const char *>(ml + (size_t)b * kKnnQueriesPerBlock);
+                    const int bytes = std::min(std::max(cnt[b], 0), kKnnQueriesPerBlock) * 4;
+                    for (int o = 0; o < bytes; o += 64) __builtin_prefetch(p0 + o, 0, 0);
+                }
+            }
+        }
         for (int pi = f * npp; pi < (f + 1) * npp; pi++) filter_pair(pi, w);
+        LatProf::mark(9);
         merge_tracks(s, f, nullptr, s.tracks[f], s.mergeable[f]);
+        LatProf::mark(10);
     };
     // frames are independent (own pair lists, own track table): one pool task each
     if (j.ext_pairs) pool->parallel_for(s.npairs_done, filter_pair, pool_threads + s.index);   // explicit pairs: lists only, the merge is the caller's

@@ -160,6 +160,9 @@ struct Slot {
     int *d_selcnt = nullptr;
     uint8_t *d_res = nullptr, *h_res = nullptr;
     size_t res_bytes = 0, res_mono_off = 0, res_resp_off = 0, ctrl_nsel_off = 0;
+    int *h_sig = nullptr;      // small GPU-selected jobs: per image, set by k_assemble behind its host-mapped results
+    bool capturing = false;    // enqueue_gpu_job is being captured into the slot's graph
+    bool gpu_small = false;    // the running GPU-selected job is a small batch: results through host-mapped memory, no copies but the flags
     int fallbacks = 0;         // jobs of this slot the host stage had to redo (a tree below the bucketing depth)
     hipEvent_t ev_s = nullptr; // k_select + k_assemble finished
     hipEvent_t ev_g = nullptr; // in front of a replayed job graph
@@ -241,6 +244,7 @@ public:
     std::vector<Slot *> slots;
     WorkerPool *pool = nullptr;
     int pool_threads = 0;
+    bool upload_pipelined = true;   // upload_u8 of a small batch: staging copy and DMA overlapped image by image
     std::atomic<int> graph_every{0};   // GPU-selected jobs replayed from a captured HIP graph: 0 never, 1 always, K all but every K-th (mcorb_rig_set_graph)
     int select_deep_cap = 4096; // k_select: largest bucket it scans node by node below the bucketing depth (MCORB_SELECT_DEEP_CAP at rig creation)
     bool gpu_select = false;   // DistributeOctTree's list discipline runs in k_select (MCORB_SELECT_GPU); else on the worker pool

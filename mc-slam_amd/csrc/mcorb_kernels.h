@@ -74,7 +74,9 @@ bool select_fits(const Geom &g);   // false: the level trees of this geometry do
 // deep_cap: a bucket with more candidates than this is not scanned node by node when a tree goes below the bucketing depth
 hipError_t launch_select(hipStream_t st, const int *tbl, const uint32_t *sorted, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg, int deep_cap = 4096);
 void launch_assemble(hipStream_t st, const uint32_t *sel_val, const int *sel_cnt, const Geom &g, const float *scale, int lap0, int lap1,
-                     uint32_t *sel, uint8_t *resp, int *nsel, int *mono, int *fallback, int nimg);
+                     uint32_t *sel, uint8_t *resp, int *nsel, int *mono, int *fallback, int nimg,
+                     // optional (all or none): host-mapped copies of sel / resp / nsel / mono and a per-image "written" flag set behind them
+                     uint32_t *sel_h = nullptr, uint8_t *resp_h = nullptr, int *nsel_h = nullptr, int *mono_h = nullptr, int *sig_h = nullptr);
 // test hook: std::sort's permutation of n 64-bit entries (upper halves compared) by one wave (wave_std_sort)
 hipError_t sort_selftest(const uint64_t *in_dev, int n, uint64_t *out_dev);
 

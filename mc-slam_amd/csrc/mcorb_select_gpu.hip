@@ -557,8 +557,12 @@ __global__ __launch_bounds__(64) void k_select(const int *__restrict__ tbl, cons
 struct AssembleParams { float scale[kMaxLevels]; int lap0, lap1; };
 __global__ __launch_bounds__(64 * kMaxLevels) void k_assemble(const uint32_t *__restrict__ sel_val, const int *__restrict__ sel_cnt, Geom g, AssembleParams P,
                                                                int selcap, uint32_t *__restrict__ sel, uint8_t *__restrict__ resp, int *__restrict__ nsel,
-                                                               int *__restrict__ mono, int *__restrict__ fallback)
+                                                               int *__restrict__ mono, int *__restrict__ fallback, uint32_t *__restrict__ sel_h,
+                                                               uint8_t *__restrict__ resp_h, int *__restrict__ nsel_h, int *__restrict__ mono_h, int *__restrict__ sig_h)
 {
+    // sel_h .. sig_h (small batches, one rig frame at a time): the host's copies of sel / responses / counts are written here too
+    // (host-mapped memory) and sig_h[img] is set behind them -- 1, or 0x100 | the image's fallback bits -- so that the host builds
+    // its keypoint records while the descriptor and matching kernels still run: no result copies at the end of the job
     // one workgroup per image, one wave per level: every wave counts its level's stereo keypoints, the counts of the levels before
     // it give its first mono / stereo position
     __shared__ int s_cnt[kMaxLevels], s_st[kMaxLevels];
@@ -587,11 +591,14 @@ __global__ __launch_bounds__(64 * kMaxLevels) void k_assemble(const uint32_t *__
         if (l < level) { monoBefore += cl - s_st[l]; stereoBefore += s_st[l]; }
     }
     if (!bad && total > g.kcap) {
-        bad = 1;
+        bad = 2;
         if (threadIdx.x == 0) atomicOr(fallback, 2);
     }
-    if (bad) {   // a level the GPU could not select (or too many keypoints): the host stage redoes the batch
-        if (threadIdx.x == 0) { nsel[img] = 0; mono[img] = 0; }
+    if (bad) {   // a level the GPU could not select (1) or too many keypoints (2): the host stage redoes the batch
+        if (threadIdx.x == 0) {
+            nsel[img] = 0; mono[img] = 0;
+            if (sig_h) { nsel_h[img] = 0; mono_h[img] = 0; __threadfence_system(); sig_h[img] = 0x100 | bad; }
+        }
         return;
     }
     uint32_t *so = sel + (size_t)img * g.kcap;
@@ -605,13 +612,27 @@ __global__ __launch_bounds__(64 * kMaxLevels) void k_assemble(const uint32_t *__
         const unsigned long long bs = __ballot(stereo), bm = __ballot(valid && !stereo);
         if (valid) {
             const int pos = stereo ? stereoIndex - sel_rank(bs) : monoIndex + sel_rank(bm);
-            so[pos] = pack_sel(level, cand_x(cd) + kMinBorder, cand_y(cd) + kMinBorder);
+            const uint32_t ps = pack_sel(level, cand_x(cd) + kMinBorder, cand_y(cd) + kMinBorder);
+            so[pos] = ps;
             ro[pos] = (uint8_t)cand_resp(cd);
+            if (sel_h) {
+                sel_h[(size_t)img * g.kcap + pos] = ps;
+                resp_h[(size_t)img * g.kcap + pos] = (uint8_t)cand_resp(cd);
+            }
         }
         stereoIndex -= __popcll(bs);
         monoIndex += __popcll(bm);
     }
     if (threadIdx.x == 0) { nsel[img] = total; mono[img] = monoAll; }
+    if (sig_h) {   // every wave's host writes are out before the image is signalled
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            nsel_h[img] = total; mono_h[img] = monoAll;
+            __threadfence_system();
+            sig_h[img] = 1;
+        }
+    }
 }
 
 // --- launch wrappers -------------------------------------------------------------------------------------------------------------
@@ -672,12 +693,13 @@ hipError_t launch_select(hipStream_t st, const int *tbl, const uint32_t *sorted,
 }
 
 void launch_assemble(hipStream_t st, const uint32_t *sel_val, const int *sel_cnt, const Geom &g, const float *scale, int lap0, int lap1,
-                     uint32_t *sel, uint8_t *resp, int *nsel, int *mono, int *fallback, int nimg)
+                     uint32_t *sel, uint8_t *resp, int *nsel, int *mono, int *fallback, int nimg, uint32_t *sel_h, uint8_t *resp_h, int *nsel_h,
+                     int *mono_h, int *sig_h)
 {
     AssembleParams P;
     for (int l = 0; l < kMaxLevels; l++) P.scale[l] = l < g.nlevels ? scale[l] : 1.f;
     P.lap0 = lap0; P.lap1 = lap1;
-    hipLaunchKernelGGL(k_assemble, dim3(nimg), dim3(64 * g.nlevels), 0, st, sel_val, sel_cnt, g, P, select_cap(g), sel, resp, nsel, mono, fallback);
+    hipLaunchKernelGGL(k_assemble, dim3(nimg), dim3(64 * g.nlevels), 0, st, sel_val, sel_cnt, g, P, select_cap(g), sel, resp, nsel, mono, fallback, sel_h, resp_h, nsel_h, mono_h, sig_h);
 }
 
 // test hook (mcorb_dev_sort_selftest): one wave sorts n entries with wave_std_sort

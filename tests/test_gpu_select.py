@@ -108,8 +108,9 @@ def _clustered_image(W, H, seed=42, patches=40):
     return base.astype(np.uint8)
 
 
+@pytest.mark.parametrize("batch", [1, 9])   # up to 8 images the results travel through host-mapped memory (signalled per image), above by copies
 @pytest.mark.parametrize("deep_cap,fallbacks", [(None, 0), ("8", 1)])
-def test_clustered_corners_below_the_bucketing_depth(mc, monkeypatch, deep_cap, fallbacks):
+def test_clustered_corners_below_the_bucketing_depth(mc, monkeypatch, deep_cap, fallbacks, batch):
     """corners only inside forty small patches: fewer non-empty buckets than the level's quota, so the tree divides nodes BELOW the
     bucketing depth.  k_select does that itself (the bucket's candidates filtered by the split lines of the node's path); with the
     scan cap turned down to 8 candidates (test knob) it raises the flag instead and the batch is redone through the host stage.
@@ -118,15 +119,18 @@ def test_clustered_corners_below_the_bucketing_depth(mc, monkeypatch, deep_cap, 
         monkeypatch.setenv("MCORB_SELECT_DEEP_CAP", deep_cap)
     W, H = 800, 600
     img = _clustered_image(W, H)
-    rig = mc.Rig(1, W, H, 1, 1, nfeatures=1000, selection=2)
-    rig.upload([img])
-    rig.extract(1)
-    ref = O.OracleExtractor(1000)(img)
-    m2, k2, d2 = rig.features(0)
-    assert ref[0] == m2 and len(ref[1]) == len(k2) and len(k2) > 300
-    for fld in ref[1].dtype.names:
-        assert np.array_equal(ref[1][fld], k2[fld]), fld
-    assert np.array_equal(ref[2], d2)
+    rig = mc.Rig(1, W, H, batch, 1, nfeatures=1000, selection=2)
+    plain = mc.synth_rig_frame(3, 1, 0, W, H)
+    imgs = [img if m == batch - 1 else plain for m in range(batch)]   # the clustered one last: the others must come out right beside it
+    rig.upload(imgs)
+    rig.extract(batch)
+    for m in (0, batch - 1):
+        ref = O.OracleExtractor(1000)(imgs[m])
+        m2, k2, d2 = rig.features(m)
+        assert ref[0] == m2 and len(ref[1]) == len(k2) and len(k2) > 300
+        for fld in ref[1].dtype.names:
+            assert np.array_equal(ref[1][fld], k2[fld]), fld
+        assert np.array_equal(ref[2], d2)
     assert rig.select_fallbacks() == fallbacks
     rig.close()
 
@@ -152,15 +156,16 @@ def test_deep_trees_on_the_gpu_random_clusters(mc, seed):
     rig.close()
 
 
-def test_lapping_partition_on_the_gpu(mc):
+@pytest.mark.parametrize("batch", [1, 9])
+def test_lapping_partition_on_the_gpu(mc, batch):
     """operator()'s stereo / mono partition (k_assemble) with a lapping area, against the oracle"""
     W, H = 640, 480
     img = mc.synth_rig_frame(1, 1, 0, W, H)
-    rig = mc.Rig(1, W, H, 1, 1, nfeatures=800, selection=2)
-    rig.upload([img])
-    rig.extract(1, lap=(200, 420))
+    rig = mc.Rig(1, W, H, batch, 1, nfeatures=800, selection=2)
+    rig.upload([mc.synth_rig_frame(2 + m, 1, 0, W, H) for m in range(batch - 1)] + [img])
+    rig.extract(batch, lap=(200, 420))
     ref = O.OracleExtractor(800)(img, lap=(200, 420))
-    m2, k2, d2 = rig.features(0)
+    m2, k2, d2 = rig.features(batch - 1)
     assert ref[0] == m2 and 0 < m2 < len(k2)
     for fld in ref[1].dtype.names:
         assert np.array_equal(ref[1][fld], k2[fld]), fld
