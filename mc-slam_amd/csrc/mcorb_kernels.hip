@@ -1774,10 +1774,16 @@ __global__ __launch_bounds__(1024) void k_knn2_finalize(const uint2 *__restrict_
         uint32_t acc = 0, t0 = 0;
         if (q < nq) {
             uint32_t k0 = 0xffffffffu, k1 = 0xffffffffu;
-            for (int c = 0; c < used; c++) {
-                const uint2 p = part[((size_t)pair * nchunks + c) * kcap + q];
-                knn_insert(p.x, k0, k1);
-                knn_insert(p.y, k0, k1);
+            for (int c = 0; c < used; c += 4) {   // four chunks' partials in flight at a time (the empty key for chunks past the end)
+                uint2 p[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    p[u] = c + u < used ? part[((size_t)pair * nchunks + c + u) * kcap + q] : uint2{0xffffffffu, 0xffffffffu};
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    knn_insert(p[u].x, k0, k1);
+                    knn_insert(p[u].y, k0, k1);
+                }
             }
             const bool v0 = k0 != 0xffffffffu, v1 = k1 != 0xffffffffu;
             const uint32_t d0 = v0 ? k0 >> 16 : 0u, d1 = v1 ? k1 >> 16 : 0u;

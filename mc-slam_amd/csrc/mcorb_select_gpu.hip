@@ -575,10 +575,20 @@ __global__ __launch_bounds__(64 * kMaxLevels) void k_assemble(const uint32_t *__
         if (level != 0) kx = __fmul_rn(kx, sc);
         return kx >= lo && kx <= hi;
     };
+    // the level's first 64 * kAsmRegs winners stay in registers between the counting and the placing pass (all loads in flight at
+    // once: one workgroup per image is latency, not bandwidth); longer lists go on from memory
+    constexpr int kAsmRegs = 8;
+    uint32_t vr[kAsmRegs];
+#pragma unroll
+    for (int u = 0; u < kAsmRegs; u++) vr[u] = u * 64 + lane < c ? v[u * 64 + lane] : 0u;
     int nst = 0;
-    for (int c0 = 0; c0 < c; c0 += 64) {
-        const int i = c0 + lane;
-        nst += __popcll(__ballot(i < c && is_stereo(v[min(i, c - 1)])));
+    if (hi >= (float)kMinBorder) {   // (no keypoint lies left of the border: the default lapping area (0, 0) has no stereo keypoints)
+#pragma unroll
+        for (int u = 0; u < kAsmRegs; u++) nst += __popcll(__ballot(u * 64 + lane < c && is_stereo(vr[u])));
+        for (int c0 = 64 * kAsmRegs; c0 < c; c0 += 64) {
+            const int i = c0 + lane;
+            nst += __popcll(__ballot(i < c && is_stereo(v[min(i, c - 1)])));
+        }
     }
     if (lane == 0) { s_cnt[level] = c; s_st[level] = nst; }
     __syncthreads();
@@ -604,10 +614,8 @@ __global__ __launch_bounds__(64 * kMaxLevels) void k_assemble(const uint32_t *__
     uint32_t *so = sel + (size_t)img * g.kcap;
     uint8_t *ro = resp + (size_t)img * g.kcap;
     int monoIndex = monoBefore, stereoIndex = total - 1 - stereoBefore;
-    for (int c0 = 0; c0 < c; c0 += 64) {
-        const int i = c0 + lane;
+    auto place = [&](int i, uint32_t cd) {
         const bool valid = i < c;
-        const uint32_t cd = valid ? v[i] : 0u;
         const bool stereo = valid && is_stereo(cd);
         const unsigned long long bs = __ballot(stereo), bm = __ballot(valid && !stereo);
         if (valid) {
@@ -622,7 +630,11 @@ __global__ __launch_bounds__(64 * kMaxLevels) void k_assemble(const uint32_t *__
         }
         stereoIndex -= __popcll(bs);
         monoIndex += __popcll(bm);
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < kAsmRegs; u++)
+        if (u * 64 < c) place(u * 64 + lane, vr[u]);
+    for (int c0 = 64 * kAsmRegs; c0 < c; c0 += 64) place(c0 + lane, c0 + lane < c ? v[c0 + lane] : 0u);
     if (threadIdx.x == 0) { nsel[img] = total; mono[img] = monoAll; }
     if (sig_h) {   // every wave's host writes are out before the image is signalled
         __threadfence_system();
