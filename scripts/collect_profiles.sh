@@ -28,6 +28,8 @@ MCORB_GRAPH=1 timeout -k 10 200 python3 scripts/latency.py 2>/dev/null | tail -1
 MCORB_GRAPH=0 timeout -k 10 200 python3 scripts/latency.py 2>/dev/null | tail -1 > $O/latency_nograph.json || true
 MCORB_SELECT=host timeout -k 10 200 python3 scripts/latency.py 2>/dev/null | tail -1 > $O/latency_hostselect.json || true
 timeout -k 10 200 tools/_build/fp4_probe > $O/fp4_probe.txt 2>&1 || true
+timeout -k 10 100 tools/_build/lat_probe > $O/lat_probe.txt 2>&1 || true
+(unset MCORB_GRAPH; bash scripts/lat_trace.sh ${1:-prof}_lt 2>&1 | grep -v rocprofv3 > $O/latency_trace.txt) || true
 timeout -k 10 200 tools/_build/valu_rates > $O/valu_rates.txt 2>&1 || true
 cp $(find $O/p_def -name '*kernel_stats.csv' | head -1) $O/stats_default.csv
 cp $(find $O/p_1s -name '*kernel_stats.csv' | head -1) $O/stats_1slot.csv

@@ -19,7 +19,8 @@ for a, b in [("bench_default.json", "bench_default.json"), ("stats_default.csv",
              ("write.txt", "pmc_write_size_summary.txt"), ("sq.txt", "pmc_sq_counters.txt"), ("calib.txt", "fetch_calibration.txt"),
              ("bow_rate.json", "bow_rate.json"), ("lf_rate.json", "lf_rate.json"), ("n1_rate.json", "n1_rate.json"),
              ("latency.json", "latency.json"), ("latency_nograph.json", "latency_nograph.json"), ("latency_hostselect.json", "latency_hostselect.json"),
-             ("fp4_probe.txt", "fp4_probe.txt"), ("valu_rates.txt", "valu_rates.txt")]:
+             ("fp4_probe.txt", "fp4_probe.txt"), ("valu_rates.txt", "valu_rates.txt"), ("lat_probe.txt", "lat_probe.txt"),
+             ("latency_trace.txt", "latency_trace.txt")]:
     if os.path.exists(os.path.join(src, a)):
         shutil.copy(os.path.join(src, a), os.path.join(P, "%s_%s" % (tag, b)))
 
