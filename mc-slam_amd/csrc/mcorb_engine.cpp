@@ -1275,6 +1275,7 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
         // stage reports that error itself)
         s.fallbacks++;
         s.graph_timing = false;
+        s.gpu_small = false;   // (the host stage uploads the whole control block and copies its results back)
         HIPCHK(hipMemcpyAsync(s.h_tbl, s.d_tbl, (size_t)nimg * s.tbl_ints_per_image * sizeof(int), hipMemcpyDeviceToHost, s.st_copy));
         HIPCHK(hipEventRecord(s.ev[3], s.st_copy));
         return run_select_and_describe(s, j, then_match);

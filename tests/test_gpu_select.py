@@ -171,3 +171,33 @@ def test_lapping_partition_on_the_gpu(mc, batch):
         assert np.array_equal(ref[1][fld], k2[fld]), fld
     assert np.array_equal(ref[2], d2)
     rig.close()
+
+
+@pytest.mark.parametrize("frames", [1, 5])   # 2 images: host-mapped results; 10 images: copied results
+def test_job_redone_by_the_host_stage_still_matches(mc, monkeypatch, frames):
+    """extract + match in one job when a level's tree makes k_select raise its flag (scan cap turned down): the host stage redoes the
+    selection, and descriptors, k-NN tables and tracks of every frame are the oracle's"""
+    monkeypatch.setenv("MCORB_SELECT_DEEP_CAP", "8")
+    W, H, C, N = 800, 600, 2, 1000
+    imgs = []
+    for f in range(frames):
+        imgs += [_clustered_image(W, H, seed=7 + f), _clustered_image(W, H, seed=7 + f, patches=44)]
+    rig = mc.Rig(C, W, H, frames, 1, nfeatures=N, selection=2)
+    rig.upload(imgs)
+    rig.process(frames)
+    assert rig.select_fallbacks() == 1
+    for f in (0, frames - 1):
+        descs = []
+        for c in range(C):
+            ref = O.OracleExtractor(N)(imgs[f * C + c])
+            m2, k2, d2 = rig.features(f * C + c)
+            assert ref[0] == m2 and len(k2) == len(ref[1]) > 100
+            assert np.array_equal(ref[1]["x"], k2["x"]) and np.array_equal(ref[1]["y"], k2["y"]) and np.array_equal(ref[2], d2)
+            descs.append(d2)
+        otr, omg = O.intra_matches(descs)
+        tr, mg = rig.tracks(f)
+        assert np.array_equal(tr, otr) and mg == omg
+        gi, gd = rig.pair_knn2(f, 0, 1)
+        oi, od = O.knn2(descs[0], descs[1])
+        assert np.array_equal(gi, oi) and np.array_equal(gd, od)
+    rig.close()
