@@ -40,6 +40,7 @@ CONFIGS = {
     "1080p8": dict(W=1920, H=1080, NCAMS=8, NFEAT=2000,
                    label="8-cam rig 1920x1080, 2000 kpts/cam, extract + all-pairs intra-rig match (configs[2])"),
 }
+HOST_CORES_EXTRA_SLOTS = 2  # the `value_host_cores` leg runs with this many slots more than jobs admitted to the GPU at once
 IMAGES_PER_LAUNCH = 512     # camera images per slot job (128 four-camera or 64 eight-camera rig frames): with the selection on the GPU the
                             # job has a latency-bound middle (k_compact, k_select, k_assemble: ~90 us whatever the batch) that larger
                             # batches amortise -- 128 images x 5 slots 37.5 k, 256 x 4 39.1 k, 512 x 4 40.0 k (profiles/r04_overlap.txt)
@@ -750,20 +751,28 @@ def main():
         allowed = sorted(os.sched_getaffinity(0))
         if len(allowed) > args.host_cores:
             os.sched_setaffinity(0, set(allowed[:args.host_cores]))
+            # With few cores the host's share of a job (keypoint records, accept lists, track merges) takes longer, so a slot
+            # spends more of its cycle off the GPU: two more slots than jobs admitted to the GPU at once (mcorb_params.gpu_jobs)
+            # keep the GPU at its four jobs.  (With all cores the plain four slots measured 4 % faster: scripts/gpujobs_sweep.sh.)
+            S_main = S
             try:
                 rig_main = rig
-                rig = mcorb.Rig(NCAMS, W, H, max_frames=fps, nslots=S, nfeatures=NFEAT, device_id=local)
+                S = S_main + HOST_CORES_EXTRA_SLOTS
+                rig = mcorb.Rig(NCAMS, W, H, max_frames=fps, nslots=S, nfeatures=NFEAT, device_id=local, gpu_jobs=S_main)
                 for s_ in range(S):
-                    rig.upload(slot_imgs[s_], slot=s_)
+                    rig.upload(slot_imgs[s_ % len(slot_imgs)], slot=s_)
                 run_steps(args.warmup, False)
                 dt_hc = timed_region(args.steps, False)
-                out["value_host_cores"] = {"cores": args.host_cores, "value": round(total_frames * args.steps / dt_hc, 2),
-                                           "engine_workers": rig.info().get("host_threads"),
+                out["value_host_cores"] = {"cores": args.host_cores, "value": round(S * fps * args.steps / dt_hc, 2),
+                                           "engine_workers": rig.info().get("host_threads"), "slots": S, "gpu_jobs": S_main,
                                            "note": "process confined to %d of the %d cores it may use (sched_setaffinity before the rig is "
-                                                   "created); `value` itself ran with all of them" % (args.host_cores, len(allowed))}
+                                                   "created), %d slots of which at most %d have their job on the GPU at a time (the others "
+                                                   "are being post-processed on the host); `value` itself ran with all cores and %d slots"
+                                                   % (args.host_cores, len(allowed), S, S_main, S_main)}
                 rig.close()
             finally:
                 rig = rig_main
+                S = S_main
                 os.sched_setaffinity(0, set(allowed))
 
     if N == 1 and not DIST and not args.no_cpu:

@@ -67,7 +67,9 @@ typedef struct mcorb_params {
     int cand_cap;         /* host-side candidate slots per image (the device list is sized for the worst case);
                              only sparse levels are copied to the host; 0 = default (max(65536, w*h/4)) */
     int selection;        /* MCORB_SELECT_*: where DistributeOctTree's list discipline runs (0 = default) */
-    int reserved[6];
+    int gpu_jobs;         /* at most this many slots' jobs on the GPU at once; further slots wait for a turn while the finished
+                             ones are post-processed on the host (0 = no limit: every slot's job goes straight to the GPU) */
+    int reserved[5];
 } mcorb_params;
 
 void mcorb_default_params(mcorb_params *p);   /* 2000, 1.2, 8, 20, 7, none, dev 0 */

@@ -25,7 +25,7 @@ class Params(C.Structure):
     _fields_ = [("nfeatures", C.c_int), ("scale_factor", C.c_float), ("nlevels", C.c_int),
                 ("ini_th_fast", C.c_int), ("min_th_fast", C.c_int), ("orientation", C.c_int),
                 ("device_id", C.c_int), ("host_threads", C.c_int), ("cand_cap", C.c_int), ("selection", C.c_int),
-                ("reserved", C.c_int * 6)]
+                ("gpu_jobs", C.c_int), ("reserved", C.c_int * 5)]
 
 
 class Camera(C.Structure):

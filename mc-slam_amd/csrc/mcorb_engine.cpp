@@ -480,6 +480,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         if (getenv("MCORB_SELECT_DEEP_CAP")) select_deep_cap = std::max(1, atoi(getenv("MCORB_SELECT_DEEP_CAP")));
         // HIP graphs: a single-slot rig (one job at a time, how MC-SLAM calls) replays its job from a captured graph -- 0.41 -> 0.35 ms
         // per rig frame; with several jobs in flight the replay measured 3 - 5 % SLOWER than launch by launch (profiles/r04_graph.txt)
+        gpu_job_limit = getenv("MCORB_GPU_JOBS") ? atoi(getenv("MCORB_GPU_JOBS")) : p.gpu_jobs;
+        if (gpu_job_limit < 0 || gpu_job_limit >= nslots) gpu_job_limit = 0;
         upload_pipelined = !(getenv("MCORB_UPLOAD_PIPE") && atoi(getenv("MCORB_UPLOAD_PIPE")) == 0);   // (A/B knob)
         graph_every = !gpu_select ? 0 : getenv("MCORB_GRAPH") ? std::max(0, atoi(getenv("MCORB_GRAPH"))) : (nslots == 1 ? 1 : 0);   // (mcorb_rig_select_mode reports what the rig really runs)
     }
@@ -1165,6 +1167,23 @@ int Rig::enqueue_gpu_job(Slot &s, const Job &j, bool then_match)
 // the host comes back when the results have landed (descriptors, the control block's sel / nsel, responses, monoIndex, flags) and
 // only builds its keypoint records from them.  A batch with a level whose tree goes below the bucketing depth (flag) is redone
 // through the host stage: run_select_and_describe on the tables, exactly the MCORB_SELECT_HOST path.
+void Rig::gpu_job_begin()
+{
+    if (!gpu_job_limit) return;
+    std::unique_lock<std::mutex> lk(gpu_jobs_m);
+    gpu_jobs_cv.wait(lk, [this] { return gpu_jobs_running < gpu_job_limit; });
+    gpu_jobs_running++;
+}
+void Rig::gpu_job_end()
+{
+    if (!gpu_job_limit) return;
+    {
+        std::lock_guard<std::mutex> lk(gpu_jobs_m);
+        gpu_jobs_running--;
+    }
+    gpu_jobs_cv.notify_one();
+}
+
 int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
 {
     if (j.nimg < 1 || j.nimg > max_images) { set_error("extract: bad image count"); return MCORB_E_ARG; }
@@ -1231,6 +1250,12 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
     };
     const int ge = graph_every.load(std::memory_order_relaxed);
     const bool graphed = ge > 0 && !j.ext_desc && (ge == 1 || (++s.job_counter % ge) != 0);
+    struct GpuTurn {   // this slot's turn on the GPU: from the first launch until the results have landed
+        Rig &r; bool held = true;
+        explicit GpuTurn(Rig &rig) : r(rig) { r.gpu_job_begin(); }
+        void done() { if (held) { held = false; r.gpu_job_end(); } }
+        ~GpuTurn() { done(); }
+    } turn(*this);
     if (graphed) {
         const Slot::GraphKey key{nimg, then_match ? 1 : 0, j.nframes, j.lap0, j.lap1, j.dist_thresh, j.ratio};
         if (!s.graph_exec || memcmp(&key, &s.graph_key, sizeof(key)) != 0) {
@@ -1266,6 +1291,7 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
         HIPCHK(wait_event(s.ev[11]));
     }
     LatProf::mark(5);
+    turn.done();
     if (s.h_overflow[0]) { set_error("candidate list of a sparse level does not fit the host buffer (raise mcorb_params.cand_cap)"); return MCORB_E_OVERFLOW; }
     if (records_done < 0) return MCORB_E_HIP;
     if (s.gpu_small && records_done < nimg) { set_error("extract: the job ended without its results"); return MCORB_E_HIP; }

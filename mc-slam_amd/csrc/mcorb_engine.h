@@ -244,6 +244,14 @@ public:
     std::vector<Slot *> slots;
     WorkerPool *pool = nullptr;
     int pool_threads = 0;
+    // admission to the GPU (mcorb_params.gpu_jobs): with more slots than jobs the GPU runs well side by side, the extra slots are
+    // the ones whose results the host is post-processing -- the GPU does not wait for the host, and is not oversubscribed either
+    int gpu_job_limit = 0;     // 0 = none
+    int gpu_jobs_running = 0;
+    std::mutex gpu_jobs_m;
+    std::condition_variable gpu_jobs_cv;
+    void gpu_job_begin();
+    void gpu_job_end();
     bool upload_pipelined = true;   // upload_u8 of a small batch: staging copy and DMA overlapped image by image
     std::atomic<int> graph_every{0};   // GPU-selected jobs replayed from a captured HIP graph: 0 never, 1 always, K all but every K-th (mcorb_rig_set_graph)
     int select_deep_cap = 4096; // k_select: largest bucket it scans node by node below the bucketing depth (MCORB_SELECT_DEEP_CAP at rig creation)

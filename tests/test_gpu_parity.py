@@ -618,6 +618,33 @@ def test_match_sets_device_resident_interframe_knn():
     rig.close()
 
 
+def test_gpu_admission_limit_changes_nothing_but_the_schedule(mc):
+    """mcorb_params.gpu_jobs: three slots, one job on the GPU at a time (the others wait for their turn or are being post-processed):
+    same features and tracks as the unlimited rig, no slot starves"""
+    C, W, H, N, F = 2, 640, 480, 800, 5     # 10 images per job: the copied-results path
+    ref = mc.Rig(C, W, H, F, 1, nfeatures=N)
+    lim = mc.Rig(C, W, H, F, 3, nfeatures=N, gpu_jobs=1)
+    batches = [[mc.synth_rig_frame(20 + b * F + f, C, c, W, H) for f in range(F) for c in range(C)] for b in range(3)]
+    for b in range(3):
+        lim.upload(batches[b], slot=b)
+    for rep in range(3):
+        for b in range(3):
+            lim.process_submit(F, slot=b)
+        for b in range(3):
+            lim.process_wait(slot=b)
+    for b in range(3):
+        ref.upload(batches[b])
+        ref.process(F)
+        for f in range(F):
+            for c in range(C):
+                assert_same_features(ref.features(f * C + c), lim.features(f * C + c, slot=b), "batch %d frame %d cam %d" % (b, f, c))
+            t1, m1 = ref.tracks(f)
+            t2, m2 = lim.tracks(f, slot=b)
+            assert np.array_equal(t1, t2) and m1 == m2
+    ref.close()
+    lim.close()
+
+
 @pytest.mark.parametrize("C,F", [(2, 1), (4, 2), (4, 3), (4, 7), (4, 9)])
 def test_knn_chunk_lengths_by_pair_count(mc, C, F):
     """k_knn2 walks the train set in chunks whose length depends on the pairs of the launch (knn_chunk_len: 256 up to 12 pairs,
