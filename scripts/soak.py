@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import mcorb  # noqa: E402
 
 C, W, H = 4, 640, 480
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 2   # rig frames per job: 2 = 8 images (results through host-mapped memory), 3 = 12 (copied)
 imgs = [mcorb.synth_rig_frame(1, C, c, W, H) for c in range(C)]
 
 
@@ -22,19 +23,19 @@ def signature(rig, slot, frame=0):
 t0 = time.time()
 ref = None
 for k in range(40):   # create / use / destroy
-    rig = mcorb.Rig(C, W, H, max_frames=2, nslots=3, nfeatures=700)
-    rig.upload(imgs + imgs, slot=k % 3)
-    rig.process(2, slot=k % 3)
-    s = signature(rig, k % 3), signature(rig, k % 3, 1)
+    rig = mcorb.Rig(C, W, H, max_frames=F, nslots=3, nfeatures=700)
+    rig.upload(imgs * F, slot=k % 3)
+    rig.process(F, slot=k % 3)
+    s = signature(rig, k % 3), signature(rig, k % 3, F - 1)
     assert s[0] == s[1]
     ref = ref or s
     assert s == ref, (k, s, ref)
     rig.close()
 print("create/destroy x40 ok, %.1f s" % (time.time() - t0))
 
-rig = mcorb.Rig(C, W, H, max_frames=2, nslots=4, nfeatures=700)
+rig = mcorb.Rig(C, W, H, max_frames=F, nslots=4, nfeatures=700)
 for s in range(4):
-    rig.upload(imgs + imgs, slot=s)
+    rig.upload(imgs * F, slot=s)
 errors = []
 
 
@@ -43,9 +44,9 @@ def worker(slots, n):
         for k in range(n):
             for s in slots:
                 if k % 2:
-                    rig.process_submit(2, slot=s)
+                    rig.process_submit(F, slot=s)
                 else:
-                    rig.process(2, slot=s)
+                    rig.process(F, slot=s)
             for s in slots:
                 if k % 2:
                     rig.process_wait(slot=s)
