@@ -478,8 +478,8 @@ int Rig::init(const mcorb_params &p, int ncams_, int W_, int H_, int max_frames_
         gpu_select = mode != MCORB_SELECT_HOST && select_fits(geom);
         // (test knob, read once here -- never from the slot drivers' threads: a getenv per launch raced with a profiler's setenv)
         if (getenv("MCORB_SELECT_DEEP_CAP")) select_deep_cap = std::max(1, atoi(getenv("MCORB_SELECT_DEEP_CAP")));
-        // HIP graphs: a single-slot rig (one job at a time, how MC-SLAM calls) replays its job from a captured graph -- 0.41 -> 0.35 ms
-        // per rig frame; with several jobs in flight the replay measured 3 - 5 % SLOWER than launch by launch (profiles/r04_graph.txt)
+        // HIP graphs: a single-slot rig (one job at a time, how MC-SLAM calls) replays its job from a captured graph -- 0.35 -> 0.29 ms
+        // per rig frame; with several jobs in flight the replay measured 3 - 5 % SLOWER than launch by launch (profiles/r04_overlap.txt)
         gpu_job_limit = getenv("MCORB_GPU_JOBS") ? atoi(getenv("MCORB_GPU_JOBS")) : p.gpu_jobs;
         if (gpu_job_limit < 0 || gpu_job_limit >= nslots) gpu_job_limit = 0;
         upload_pipelined = !(getenv("MCORB_UPLOAD_PIPE") && atoi(getenv("MCORB_UPLOAD_PIPE")) == 0);   // (A/B knob)
