@@ -41,6 +41,7 @@ R["K_SEL"] = "%.0f" % sel
 ksum = sum(iso[k] for k in short) + sel + 12
 R["KSUM"] = "%.0f" % ksum
 R["KIDEAL"] = "%.1f" % (32 / (ksum * 1e-6) / 1000)
+R["PIPEF"] = "%.0f" % (100 * d["value"] / (32 / (ksum * 1e-6)))
 parts = sorted(glob.glob(os.path.join(ROOT, "docs", "design", "*.md")))
 text = "".join(open(p).read() + ("" if open(p).read().endswith("\n\n") else "\n") for p in parts)
 for k, v in R.items():
