@@ -30,7 +30,7 @@ def main():
     print(asm[start])
     blocks, cur = [], ["entry", 0, 0, 0, 0]
     for l in body[1:]:
-        m = re.match(r"^(\.LBB\S+):\s*(;.*)?", l)
+        m = re.match(r"^(\.LBB\S+):\s*(;.*)?", l) or re.match(r"^; (%bb\.\d+):\s*(;.*)?", l)   # (fall-through blocks have no label, only a comment)
         if m:
             blocks.append(cur)
             cur = [m.group(1) + " " + (m.group(2) or ""), 0, 0, 0, 0]
