@@ -794,6 +794,10 @@ static void flush()
 
 int Rig::execute(Slot &s, const Job &j)
 {
+    // A stale error of this thread is not this job's: e.g. an elapsed-time query (mcorb_rig_last_timing, the fallback path's own
+    // accounting) on events that a captured graph holds as nodes and no stream ever recorded leaves "invalid resource handle" behind,
+    // and the next hipGetLastError() check -- possibly another rig's job on the same thread -- would trip over it.
+    (void)hipGetLastError();
     int st = MCORB_OK;
     switch (j.kind) {
     case Job::EXTRACT:
