@@ -325,6 +325,13 @@ void WorkerPool::parallel_for(int n, const std::function<void(int, int)> &fn, in
 // ---------------------------------------------------------------------------
 // Rig
 // ---------------------------------------------------------------------------
+// Elapsed milliseconds between two events of a finished job; 0 when either was not recorded on a stream (a job that ran from its
+// captured graph holds them as graph nodes).  A failed query must not stay behind as the thread's "last error".
+static inline void ev_elapsed(float *ms, hipEvent_t a, hipEvent_t b)
+{
+    if (hipEventElapsedTime(ms, a, b) != hipSuccess) { *ms = 0.f; (void)hipGetLastError(); }
+}
+
 hipError_t Rig::wait_event(hipEvent_t ev) const
 {
     if (wait_mode != 2) return hipEventSynchronize(ev);   // spins, or sleeps on the interrupt (event flag)
@@ -1045,15 +1052,15 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
         LatProf::mark(5);
         s.nimg_done = nimg;
         float a = 0, c = 0, t = 0;
-        (void)hipEventElapsedTime(&a, s.ev[0], s.ev[2]);
-        (void)hipEventElapsedTime(&c, s.ev[5], s.ev[6]);
+        ev_elapsed(&a, s.ev[0], s.ev[2]);
+        ev_elapsed(&c, s.ev[5], s.ev[6]);
         s.timing[0] = a * 1000.f;
         s.timing[2] = c * 1000.f;
         s.timing[8] = 0.f;
         s.timing[9] = c * 1000.f;
-        (void)hipEventElapsedTime(&t, s.ev[0], s.ev[1]); s.timing[4] = t * 1000.f;
-        (void)hipEventElapsedTime(&t, s.ev[1], s.ev[2]); s.timing[5] = t * 1000.f;
-        (void)hipEventElapsedTime(&t, s.ev[2], s.ev_c); s.timing[6] = t * 1000.f;
+        ev_elapsed(&t, s.ev[0], s.ev[1]); s.timing[4] = t * 1000.f;
+        ev_elapsed(&t, s.ev[1], s.ev[2]); s.timing[5] = t * 1000.f;
+        ev_elapsed(&t, s.ev[2], s.ev_c); s.timing[6] = t * 1000.f;
         return MCORB_OK;
     }
     // one H2D copy of the control block: counts, pair list, packed selected keypoints
@@ -1089,16 +1096,16 @@ int Rig::run_select_and_describe(Slot &s, const Job &j, bool then_match)
             for (size_t k = 0; k < s.kps[m].size(); k++) s.kps[m][k].angle = s.h_angles[(size_t)m * geom.kcap + k];
     s.nimg_done = nimg;
     float a = 0, b = 0, c = 0, t = 0;
-    (void)hipEventElapsedTime(&a, s.ev[0], s.ev[2]);
-    (void)hipEventElapsedTime(&b, s.ev_c, s.ev[4]);
-    (void)hipEventElapsedTime(&c, s.ev[5], s.ev[6]);
+    ev_elapsed(&a, s.ev[0], s.ev[2]);
+    ev_elapsed(&b, s.ev_c, s.ev[4]);
+    ev_elapsed(&c, s.ev[5], s.ev[6]);
     s.timing[0] = a * 1000.f;
     s.timing[2] = (b + c) * 1000.f;
     s.timing[8] = b * 1000.f;   // k_blur
     s.timing[9] = c * 1000.f;   // k_describe
-    (void)hipEventElapsedTime(&t, s.ev[0], s.ev[1]); s.timing[4] = t * 1000.f;   // pyramid launches
-    (void)hipEventElapsedTime(&t, s.ev[1], s.ev[2]); s.timing[5] = t * 1000.f;   // k_fast_cells
-    (void)hipEventElapsedTime(&t, s.ev[2], s.ev_c); s.timing[6] = t * 1000.f;   // k_compact (the table DMA behind it is not included)
+    ev_elapsed(&t, s.ev[0], s.ev[1]); s.timing[4] = t * 1000.f;   // pyramid launches
+    ev_elapsed(&t, s.ev[1], s.ev[2]); s.timing[5] = t * 1000.f;   // k_fast_cells
+    ev_elapsed(&t, s.ev[2], s.ev_c); s.timing[6] = t * 1000.f;   // k_compact (the table DMA behind it is not included)
     return MCORB_OK;
 }
 
@@ -1316,23 +1323,23 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
     float a = 0, b = 0, c = 0, t = 0;
     if (graphed) {   // one interval: the whole job
         for (float &v : s.timing) v = 0.f;
-        (void)hipEventElapsedTime(&a, s.ev_g, s.ev[10]);
+        ev_elapsed(&a, s.ev_g, s.ev[10]);
         s.timing[0] = a * 1000.f;
         s.graph_timing = true;
         return MCORB_OK;
     }
     s.graph_timing = false;
-    (void)hipEventElapsedTime(&a, s.ev[0], s.ev[2]);
-    (void)hipEventElapsedTime(&b, s.ev[3], s.ev[4]);
-    (void)hipEventElapsedTime(&c, s.ev[5], s.ev[6]);
+    ev_elapsed(&a, s.ev[0], s.ev[2]);
+    ev_elapsed(&b, s.ev[3], s.ev[4]);
+    ev_elapsed(&c, s.ev[5], s.ev[6]);
     s.timing[0] = a * 1000.f;
     s.timing[2] = (b + c) * 1000.f;
     s.timing[8] = b * 1000.f;
     s.timing[9] = c * 1000.f;
-    (void)hipEventElapsedTime(&t, s.ev[0], s.ev[1]); s.timing[4] = t * 1000.f;
-    (void)hipEventElapsedTime(&t, s.ev[1], s.ev[2]); s.timing[5] = t * 1000.f;
-    (void)hipEventElapsedTime(&t, s.ev[2], s.ev_c); s.timing[6] = t * 1000.f;
-    (void)hipEventElapsedTime(&t, s.ev_c, s.ev_s); s.timing[1] = t * 1000.f;   // k_select + k_assemble
+    ev_elapsed(&t, s.ev[0], s.ev[1]); s.timing[4] = t * 1000.f;
+    ev_elapsed(&t, s.ev[1], s.ev[2]); s.timing[5] = t * 1000.f;
+    ev_elapsed(&t, s.ev[2], s.ev_c); s.timing[6] = t * 1000.f;
+    ev_elapsed(&t, s.ev_c, s.ev_s); s.timing[1] = t * 1000.f;   // k_select + k_assemble
     return MCORB_OK;
 }
 
@@ -1572,8 +1579,8 @@ int Rig::finish_match(Slot &s, const Job &j)
     else if (s.nframes_done == 1) one_frame(0, 0);   // (spreading one frame's pairs over the pool was slower: wake-ups)
     if (s.npairs_done > 0 && !s.graph_timing) {
         float m = 0;
-        (void)hipEventElapsedTime(&m, s.ev[7], s.ev[9]); s.timing[3] = m * 1000.f;
-        (void)hipEventElapsedTime(&m, s.ev_e, s.ev[8]); s.timing[7] = m * 1000.f;   // k_knn2 (k_expand in front of it: timing[3] - [7] - finalize)
+        ev_elapsed(&m, s.ev[7], s.ev[9]); s.timing[3] = m * 1000.f;
+        ev_elapsed(&m, s.ev_e, s.ev[8]); s.timing[7] = m * 1000.f;   // k_knn2 (k_expand in front of it: timing[3] - [7] - finalize)
     }
     return MCORB_OK;
 }
