@@ -1139,8 +1139,7 @@ int Rig::enqueue_gpu_job(Slot &s, const Job &j, bool then_match)
     HIPCHK(launch_select(s.st, s.d_tbl, s.d_sorted, geom, s.d_selval, s.d_selcnt, d_flags, nimg, select_deep_cap));
     if (small)
         launch_assemble(s.st, s.d_selval, s.d_selcnt, geom, tab.scale, j.lap0, j.lap1, s.d_sel, s.d_res + s.res_resp_off, s.d_nsel,
-                        reinterpret_cast<int *>(s.d_res + s.res_mono_off), d_flags, nimg, s.h_sel, s.h_res + s.res_resp_off, s.h_nsel,
-                        reinterpret_cast<int *>(s.h_res + s.res_mono_off), s.h_sig);
+                        reinterpret_cast<int *>(s.d_res + s.res_mono_off), d_flags, nimg, s.h_sel, s.h_res + s.res_resp_off, s.h_sig);
     else
         launch_assemble(s.st, s.d_selval, s.d_selcnt, geom, tab.scale, j.lap0, j.lap1, s.d_sel, s.d_res + s.res_resp_off, s.d_nsel,
                         reinterpret_cast<int *>(s.d_res + s.res_mono_off), d_flags, nimg);
@@ -1203,10 +1202,10 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
     s.small_job = false;
     s.h_overflow[0] = 0;
     s.nimg_done = nimg;
-    s.gpu_small = nimg <= kSmallBatch && params.orientation == 0 && !blur_planes && !j.ext_desc;
+    s.gpu_small = nimg <= kSmallBatch && params.orientation == 0 && !blur_planes && !j.ext_desc && geom.kcap <= kSelSignalMaxCount;
     if (then_match) TRY(prepare_match(s, j));
     if (s.gpu_small)
-        for (int m = 0; m < nimg; m++) reinterpret_cast<volatile int *>(s.h_sig)[m] = 0;
+        for (int m = 0; m < nimg; m++) reinterpret_cast<volatile unsigned long long *>(s.h_sig)[m] = 0;
     s.blur_valid = blur_planes;
     // The job is the same ~20 launches and copies every time: captured once per (slot, shape of the job) into a HIP graph and
     // replayed with one call -- the CPU side of a job drops from ~20 runtime calls to one, the gaps between its kernels shrink.
@@ -1239,9 +1238,9 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
     // a small batch: the records are built here, image by image as k_assemble signals them, while the descriptor and matching
     // kernels still run; returns the number of images done (all of them unless the job ended without signalling: an error), -1 on
     // a HIP error
-    int records_done = 0, small_flags = 0;
+    int records_done = 0, small_flags = 0, early_stale = 0;
     auto records_early = [&](hipEvent_t end) {
-        const volatile int *sig = s.h_sig;
+        const volatile unsigned long long *sig = s.h_sig;
         for (int m = 0; m < nimg; m++) {
             unsigned spins = 0;
             while (!sig[m]) {
@@ -1254,7 +1253,19 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
                 else __builtin_ia32_pause();
             }
             std::atomic_thread_fence(std::memory_order_acquire);
-            if (sig[m] & 0x100) small_flags |= sig[m] & 3;
+            const unsigned long long w = sig[m];   // count and monoIndex travel in the signal word itself (sel_signal())
+            small_flags |= (int)((w >> 1) & 3);
+            const int n = (int)((w >> 3) & 0x3fffu);
+            s.h_nsel[m] = n;
+            reinterpret_cast<int *>(s.h_res + s.res_mono_off)[m] = (int)((w >> 17) & 0x3fffu);
+            // ... and so does a checksum of the sel / response values k_assemble sent: values the word does not vouch for have not
+            // all landed yet (never seen with the atomic signal; cheap to be sure) -- this image and the ones behind it are expanded
+            // after the job's end event instead
+            uint32_t x = 0;
+            const uint32_t *sel = s.h_sel + (size_t)m * geom.kcap;
+            const uint8_t *rs = s.h_res + s.res_resp_off + (size_t)m * geom.kcap;
+            for (int k = 0; k < n; k++) x ^= sel_check(sel[k], rs[k], k);
+            if (x != (uint32_t)(w >> 32)) { early_stale++; return; }
             records(m);
             records_done = m + 1;
         }
@@ -1305,7 +1316,21 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
     turn.done();
     if (s.h_overflow[0]) { set_error("candidate list of a sparse level does not fit the host buffer (raise mcorb_params.cand_cap)"); return MCORB_E_OVERFLOW; }
     if (records_done < 0) return MCORB_E_HIP;
-    if (s.gpu_small && records_done < nimg) { set_error("extract: the job ended without its results"); return MCORB_E_HIP; }
+    if (s.gpu_small && records_done < nimg) {
+        // the job is over: every signal word and everything behind it has landed
+        for (int m = records_done; m < nimg; m++) {
+            const unsigned long long w = reinterpret_cast<const volatile unsigned long long *>(s.h_sig)[m];
+            if (!(w & 1)) { set_error("extract: the job ended without its results"); return MCORB_E_HIP; }
+            small_flags |= (int)((w >> 1) & 3);
+            s.h_nsel[m] = (int)((w >> 3) & 0x3fffu);
+            reinterpret_cast<int *>(s.h_res + s.res_mono_off)[m] = (int)((w >> 17) & 0x3fffu);
+        }
+        if (early_stale) {
+            s.stale_reads += early_stale;
+            static const bool dbg = getenv("MCORB_DEBUG_EMPTY") != nullptr;
+            if (dbg) fprintf(stderr, "[mcorb debug] image %d: values read ahead of the signal word's checksum; records redone after the end event\n", records_done);
+        }
+    }
     const int flags = s.gpu_small ? small_flags : reinterpret_cast<const int *>(s.h_res)[0];
     if (flags) {
         // the host stage on the same tables (bit 0: a tree below the bucketing depth; bit 1: more than kcap keypoints -- the host
@@ -1318,6 +1343,35 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
         return run_select_and_describe(s, j, then_match);
     }
     if (records_done < nimg) pool->parallel_for(nimg, [&](int m, int) { records(m); }, pool_threads + s.index);
+    {
+        // MCORB_DEBUG_EMPTY=1: an image that came back without keypoints is looked at again, after the job: what the device holds
+        // (counts of FAST candidates, per-level selections, nsel) against what the host read -- to tell "nothing to find" from a
+        // result that was read before it had landed
+        static const bool dbg_empty = getenv("MCORB_DEBUG_EMPTY") != nullptr;
+        if (dbg_empty)
+            for (int m = 0; m < nimg; m++) {
+                if (!s.kps[m].empty()) continue;
+                (void)hipStreamSynchronize(s.st);
+                std::vector<int> cc(geom.cells), sc(geom.nlevels);
+                int dn = -1;
+                (void)hipMemcpy(cc.data(), s.d_cellcnt + (size_t)m * geom.cells, cc.size() * sizeof(int), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(sc.data(), s.d_selcnt + (size_t)m * geom.nlevels, sc.size() * sizeof(int), hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&dn, s.d_nsel + m, sizeof(int), hipMemcpyDeviceToHost);
+                long long cand = 0;
+                for (int v : cc) cand += v;
+                long long px = 0;
+                std::vector<uint8_t> row(W);
+                (void)hipMemcpy(row.data(), s.d_pyr + (size_t)m * geom.imgBytes + geom.lv[0].off + (size_t)(H / 2) * geom.lv[0].pitch, W, hipMemcpyDeviceToHost);
+                for (uint8_t v : row) px += v;
+                fprintf(stderr, "[mcorb debug empty] image %d of %d: small %d graphed %d | host: sig %d nsel %d | device now: nsel %d, FAST candidates %lld, "
+                                "selected per level", m, nimg, (int)s.gpu_small, (int)graphed, s.gpu_small ? (int)(s.h_sig[m] & 0xff) : -1, s.h_nsel[m], dn, cand);
+                for (int v : sc) fprintf(stderr, " %d", v);
+                fprintf(stderr, " | middle row of level 0 sums to %lld (staging row: ", px);
+                long long hx = 0;
+                for (int x = 0; x < W; x++) hx += s.h_stage[(size_t)m * W * H + (size_t)(H / 2) * W + x];
+                fprintf(stderr, "%lld)\n", hx);
+            }
+    }
     if (then_match && !j.ext_desc)
         for (size_t i = 0; i < s.match_counts.size(); i++) s.match_counts[i] = s.h_nsel[s.match_sets[i]];
     float a = 0, b = 0, c = 0, t = 0;

@@ -160,9 +160,10 @@ struct Slot {
     int *d_selcnt = nullptr;
     uint8_t *d_res = nullptr, *h_res = nullptr;
     size_t res_bytes = 0, res_mono_off = 0, res_resp_off = 0, ctrl_nsel_off = 0;
-    int *h_sig = nullptr;      // small GPU-selected jobs: per image, set by k_assemble behind its host-mapped results
+    unsigned long long *h_sig = nullptr;      // small GPU-selected jobs: per image, set by k_assemble behind its host-mapped results
     bool capturing = false;    // enqueue_gpu_job is being captured into the slot's graph
     bool gpu_small = false;    // the running GPU-selected job is a small batch: results through host-mapped memory, no copies but the flags
+    int stale_reads = 0;       // small batches: images whose early read did not match the signal word's checksum (redone after the end event)
     int fallbacks = 0;         // jobs of this slot the host stage had to redo (a tree below the bucketing depth)
     hipEvent_t ev_s = nullptr; // k_select + k_assemble finished
     hipEvent_t ev_g = nullptr; // in front of a replayed job graph

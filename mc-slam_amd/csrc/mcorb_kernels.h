@@ -75,8 +75,21 @@ bool select_fits(const Geom &g);   // false: the level trees of this geometry do
 hipError_t launch_select(hipStream_t st, const int *tbl, const uint32_t *sorted, const Geom &g, uint32_t *sel_val, int *sel_cnt, int *fallback, int nimg, int deep_cap = 4096);
 void launch_assemble(hipStream_t st, const uint32_t *sel_val, const int *sel_cnt, const Geom &g, const float *scale, int lap0, int lap1,
                      uint32_t *sel, uint8_t *resp, int *nsel, int *mono, int *fallback, int nimg,
-                     // optional (all or none): host-mapped copies of sel / resp / nsel / mono and a per-image "written" flag set behind them
-                     uint32_t *sel_h = nullptr, uint8_t *resp_h = nullptr, int *nsel_h = nullptr, int *mono_h = nullptr, int *sig_h = nullptr);
+                     // optional (all or none): host-mapped copies of sel / resp and a per-image signal word set behind them
+                     uint32_t *sel_h = nullptr, uint8_t *resp_h = nullptr, unsigned long long *sig_h = nullptr);
+// The signal word of an image (k_assemble -> host, small batches): bit 0 done, bits 1 - 2 fallback code (1: a level the GPU could not
+// select, 2: more than kcap keypoints), bits 3 - 16 keypoint count, bits 17 - 30 monoIndex (both < 16384: kSelSignalMaxCount),
+// bits 32 - 63 the XOR of sel_check() over the image's keypoints.
+constexpr int kSelSignalMaxCount = 16383;
+__host__ __device__ inline unsigned long long sel_signal(int bad, int count, int mono, uint32_t check)
+{
+    return 1ull | ((unsigned long long)(bad & 3) << 1) | ((unsigned long long)(count & 0x3fff) << 3) | ((unsigned long long)(mono & 0x3fff) << 17) |
+           ((unsigned long long)check << 32);
+}
+__host__ __device__ inline uint32_t sel_check(uint32_t packed_sel, uint8_t resp, int pos)
+{
+    return (packed_sel ^ ((uint32_t)resp << 24) ^ ((uint32_t)pos * 0x9E3779B1u)) * 0x85EBCA6Bu;
+}
 // test hook: std::sort's permutation of n 64-bit entries (upper halves compared) by one wave (wave_std_sort)
 hipError_t sort_selftest(const uint64_t *in_dev, int n, uint64_t *out_dev);
 

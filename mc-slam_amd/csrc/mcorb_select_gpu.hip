@@ -558,14 +558,21 @@ struct AssembleParams { float scale[kMaxLevels]; int lap0, lap1; };
 __global__ __launch_bounds__(64 * kMaxLevels) void k_assemble(const uint32_t *__restrict__ sel_val, const int *__restrict__ sel_cnt, Geom g, AssembleParams P,
                                                                int selcap, uint32_t *__restrict__ sel, uint8_t *__restrict__ resp, int *__restrict__ nsel,
                                                                int *__restrict__ mono, int *__restrict__ fallback, uint32_t *__restrict__ sel_h,
-                                                               uint8_t *__restrict__ resp_h, int *__restrict__ nsel_h, int *__restrict__ mono_h, int *__restrict__ sig_h)
+                                                               uint8_t *__restrict__ resp_h, unsigned long long *sig_h)
 {
-    // sel_h .. sig_h (small batches, one rig frame at a time): the host's copies of sel / responses / counts are written here too
-    // (host-mapped memory) and sig_h[img] is set behind them -- 1, or 0x100 | the image's fallback bits -- so that the host builds
-    // its keypoint records while the descriptor and matching kernels still run: no result copies at the end of the job
+    // sel_h, resp_h, sig_h (small batches, one rig frame at a time): the host's copies of sel / responses are written here too
+    // (host-mapped memory) and sig_h[img] is set behind them, so that the host builds its keypoint records while the descriptor and
+    // matching kernels still run: no result copies at the end of the job.  The signal word carries everything else the host
+    // needs (sel_signal(), mcorb_kernels.h: done, fallback code, keypoint count, monoIndex, and a checksum of the sel / response
+    // values sent) and is written with a system-scope atomic exchange behind a system-scope fence: over PCIe an atomic is a
+    // non-posted request, which may not pass the posted writes in front of it, whereas a plain store behind the same fence was seen by
+    // the host BEFORE the count written just ahead of it (once in ~10^4 jobs: scripts/stress_consistency.py).  The checksum makes
+    // the hand-off self-checking whatever the fabric does: a host that reads values the word does not vouch for redoes the image's
+    // records after the job's end event.
     // one workgroup per image, one wave per level: every wave counts its level's stereo keypoints, the counts of the levels before
     // it give its first mono / stereo position
     __shared__ int s_cnt[kMaxLevels], s_st[kMaxLevels];
+    __shared__ uint32_t s_chk[kMaxLevels];   // (its own array: a slow wave may still be reading s_st when a fast one gets here)
     const int lane = sel_lane(), level = threadIdx.x >> 6, img = blockIdx.x;
     const int c = sel_cnt[(size_t)img * g.nlevels + level];
     const uint32_t *v = sel_val + ((size_t)img * g.nlevels + level) * selcap;
@@ -607,13 +614,14 @@ __global__ __launch_bounds__(64 * kMaxLevels) void k_assemble(const uint32_t *__
     if (bad) {   // a level the GPU could not select (1) or too many keypoints (2): the host stage redoes the batch
         if (threadIdx.x == 0) {
             nsel[img] = 0; mono[img] = 0;
-            if (sig_h) { nsel_h[img] = 0; mono_h[img] = 0; __threadfence_system(); sig_h[img] = 0x100 | bad; }
+            if (sig_h) __hip_atomic_exchange(&sig_h[img], sel_signal(bad, 0, 0, 0), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
     uint32_t *so = sel + (size_t)img * g.kcap;
     uint8_t *ro = resp + (size_t)img * g.kcap;
     int monoIndex = monoBefore, stereoIndex = total - 1 - stereoBefore;
+    uint32_t chk = 0;   // XOR of what this lane sends to the host (sel_check): the host recomputes it over what it reads
     auto place = [&](int i, uint32_t cd) {
         const bool valid = i < c;
         const bool stereo = valid && is_stereo(cd);
@@ -626,6 +634,7 @@ __global__ __launch_bounds__(64 * kMaxLevels) void k_assemble(const uint32_t *__
             if (sel_h) {
                 sel_h[(size_t)img * g.kcap + pos] = ps;
                 resp_h[(size_t)img * g.kcap + pos] = (uint8_t)cand_resp(cd);
+                chk ^= sel_check(ps, (uint8_t)cand_resp(cd), pos);
             }
         }
         stereoIndex -= __popcll(bs);
@@ -637,12 +646,15 @@ __global__ __launch_bounds__(64 * kMaxLevels) void k_assemble(const uint32_t *__
     for (int c0 = 64 * kAsmRegs; c0 < c; c0 += 64) place(c0 + lane, c0 + lane < c ? v[c0 + lane] : 0u);
     if (threadIdx.x == 0) { nsel[img] = total; mono[img] = monoAll; }
     if (sig_h) {   // every wave's host writes are out before the image is signalled
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) chk ^= __shfl_xor(chk, o);
+        if (lane == 0) s_chk[level] = chk;
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) {
-            nsel_h[img] = total; mono_h[img] = monoAll;
-            __threadfence_system();
-            sig_h[img] = 1;
+            uint32_t x = 0;
+            for (int l = 0; l < g.nlevels; l++) x ^= s_chk[l];
+            __hip_atomic_exchange(&sig_h[img], sel_signal(0, total, monoAll, x), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -705,13 +717,13 @@ hipError_t launch_select(hipStream_t st, const int *tbl, const uint32_t *sorted,
 }
 
 void launch_assemble(hipStream_t st, const uint32_t *sel_val, const int *sel_cnt, const Geom &g, const float *scale, int lap0, int lap1,
-                     uint32_t *sel, uint8_t *resp, int *nsel, int *mono, int *fallback, int nimg, uint32_t *sel_h, uint8_t *resp_h, int *nsel_h,
-                     int *mono_h, int *sig_h)
+                     uint32_t *sel, uint8_t *resp, int *nsel, int *mono, int *fallback, int nimg, uint32_t *sel_h, uint8_t *resp_h,
+                     unsigned long long *sig_h)
 {
     AssembleParams P;
     for (int l = 0; l < kMaxLevels; l++) P.scale[l] = l < g.nlevels ? scale[l] : 1.f;
     P.lap0 = lap0; P.lap1 = lap1;
-    hipLaunchKernelGGL(k_assemble, dim3(nimg), dim3(64 * g.nlevels), 0, st, sel_val, sel_cnt, g, P, select_cap(g), sel, resp, nsel, mono, fallback, sel_h, resp_h, nsel_h, mono_h, sig_h);
+    hipLaunchKernelGGL(k_assemble, dim3(nimg), dim3(64 * g.nlevels), 0, st, sel_val, sel_cnt, g, P, select_cap(g), sel, resp, nsel, mono, fallback, sel_h, resp_h, sig_h);
 }
 
 // test hook (mcorb_dev_sort_selftest): one wave sorts n entries with wave_std_sort
