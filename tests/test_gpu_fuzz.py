@@ -30,3 +30,21 @@ def test_soak_create_destroy_and_threads():
     """scripts/soak.py: 40 create/use/destroy cycles, then two threads mixing synchronous and asynchronous calls on four slots."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "soak.py")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "x40 ok" in out.stdout and "mixed) ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("frames", ["2", "3"])   # 8 images per job: results through host-mapped memory; 12: copied
+def test_soak_both_result_paths_with_admission_limit(frames):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "soak.py"), frames], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, MCORB_GPU_JOBS="2"))
+    assert out.returncode == 0 and "x40 ok" in out.stdout and "mixed) ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_repeated_and_alternating_images_agree():
+    """scripts/stress_consistency.py: a fresh extractor per case, two images alternating A B A B; a result the host read before it had
+    landed would show as an empty first result or as the other image's keypoints (the long form of this run found the one-in-10^4
+    ordering problem of the first small-batch hand-off)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "stress_consistency.py"), "300", "17"], capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and " 0 bad" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
