@@ -48,3 +48,13 @@ def test_repeated_and_alternating_images_agree():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "stress_consistency.py"), "300", "17"], capture_output=True, text=True,
                          timeout=600)
     assert out.returncode == 0 and " 0 bad" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("slots,gpu_jobs", [("4", "0"), ("5", "3")])
+def test_pipeline_results_stay_the_same_under_load(slots, gpu_jobs):
+    """scripts/stress_pipeline.py: rolling submission of 64-image jobs on several slots; every job's keypoints, descriptors and tracks
+    must equal the slot's first round, and slot 0's first frame the oracle's"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "stress_pipeline.py"), "40", slots, "16", gpu_jobs], capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and " 0 bad" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
