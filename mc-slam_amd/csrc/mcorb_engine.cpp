@@ -1255,7 +1255,7 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
             std::atomic_thread_fence(std::memory_order_acquire);
             const unsigned long long w = sig[m];   // count and monoIndex travel in the signal word itself (sel_signal())
             small_flags |= (int)((w >> 1) & 3);
-            const int n = (int)((w >> 3) & 0x3fffu);
+            const int n = std::min((int)((w >> 3) & 0x3fffu), geom.kcap);   // (k_assemble never signals more than kcap; the clamp is for the reads below)
             s.h_nsel[m] = n;
             reinterpret_cast<int *>(s.h_res + s.res_mono_off)[m] = (int)((w >> 17) & 0x3fffu);
             // ... and so does a checksum of the sel / response values k_assemble sent: values the word does not vouch for have not
@@ -1322,7 +1322,7 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
             const unsigned long long w = reinterpret_cast<const volatile unsigned long long *>(s.h_sig)[m];
             if (!(w & 1)) { set_error("extract: the job ended without its results"); return MCORB_E_HIP; }
             small_flags |= (int)((w >> 1) & 3);
-            s.h_nsel[m] = (int)((w >> 3) & 0x3fffu);
+            s.h_nsel[m] = std::min((int)((w >> 3) & 0x3fffu), geom.kcap);
             reinterpret_cast<int *>(s.h_res + s.res_mono_off)[m] = (int)((w >> 17) & 0x3fffu);
         }
         if (early_stale) {
