@@ -64,3 +64,31 @@ for t in th:
 assert not errors, errors
 print("2 threads x 150 rounds x 2 slots (sync + async mixed) ok, %.1f s" % (time.time() - t0))
 rig.close()
+
+# two rigs of different sizes, each driven by its own thread at the same time (separate worker pools, separate graphs)
+def rig_worker(w, h, n, out):
+    try:
+        r = mcorb.Rig(C, w, h, max_frames=1, nslots=1, nfeatures=600)
+        im = [mcorb.synth_rig_frame(3, C, c, w, h) for c in range(C)]
+        first = None
+        for k in range(n):
+            r.upload(im)
+            r.process(1)
+            tr, mg = r.tracks(0)
+            s_ = int(tr.sum()) * 31 + mg + sum(int(r.features(c)[2].sum()) for c in range(C))
+            first = first if first is not None else s_
+            assert s_ == first, (w, h, k)
+        r.close()
+    except Exception as e:   # noqa: BLE001
+        out.append(e)
+
+
+t0 = time.time()
+errs = []
+th = [threading.Thread(target=rig_worker, args=(w, h, 300, errs)) for w, h in ((640, 480), (752, 480), (512, 384))]
+for t in th:
+    t.start()
+for t in th:
+    t.join()
+assert not errs, errs
+print("3 rigs x 300 frames in parallel threads ok, %.1f s" % (time.time() - t0))
