@@ -1254,10 +1254,10 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
             }
             std::atomic_thread_fence(std::memory_order_acquire);
             const unsigned long long w = sig[m];   // count and monoIndex travel in the signal word itself (sel_signal())
-            small_flags |= (int)((w >> 1) & 3);
-            const int n = std::min((int)((w >> 3) & 0x3fffu), geom.kcap);   // (k_assemble never signals more than kcap; the clamp is for the reads below)
+            small_flags |= sel_signal_bad(w);
+            const int n = std::min(sel_signal_count(w), geom.kcap);   // (k_assemble never signals more than kcap; the clamp is for the reads below)
             s.h_nsel[m] = n;
-            reinterpret_cast<int *>(s.h_res + s.res_mono_off)[m] = (int)((w >> 17) & 0x3fffu);
+            reinterpret_cast<int *>(s.h_res + s.res_mono_off)[m] = sel_signal_mono(w);
             // ... and so does a checksum of the sel / response values k_assemble sent: values the word does not vouch for have not
             // all landed yet (never seen with the atomic signal; cheap to be sure) -- this image and the ones behind it are expanded
             // after the job's end event instead
@@ -1265,7 +1265,7 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
             const uint32_t *sel = s.h_sel + (size_t)m * geom.kcap;
             const uint8_t *rs = s.h_res + s.res_resp_off + (size_t)m * geom.kcap;
             for (int k = 0; k < n; k++) x ^= sel_check(sel[k], rs[k], k);
-            if (x != (uint32_t)(w >> 32)) { early_stale++; return; }
+            if (x != sel_signal_check(w)) { early_stale++; return; }
             records(m);
             records_done = m + 1;
         }
@@ -1320,10 +1320,10 @@ int Rig::run_gpu_selected(Slot &s, const Job &j, bool then_match)
         // the job is over: every signal word and everything behind it has landed
         for (int m = records_done; m < nimg; m++) {
             const unsigned long long w = reinterpret_cast<const volatile unsigned long long *>(s.h_sig)[m];
-            if (!(w & 1)) { set_error("extract: the job ended without its results"); return MCORB_E_HIP; }
-            small_flags |= (int)((w >> 1) & 3);
-            s.h_nsel[m] = std::min((int)((w >> 3) & 0x3fffu), geom.kcap);
-            reinterpret_cast<int *>(s.h_res + s.res_mono_off)[m] = (int)((w >> 17) & 0x3fffu);
+            if (!sel_signal_done(w)) { set_error("extract: the job ended without its results"); return MCORB_E_HIP; }
+            small_flags |= sel_signal_bad(w);
+            s.h_nsel[m] = std::min(sel_signal_count(w), geom.kcap);
+            reinterpret_cast<int *>(s.h_res + s.res_mono_off)[m] = sel_signal_mono(w);
         }
         if (early_stale) {
             s.stale_reads += early_stale;

@@ -86,6 +86,11 @@ __host__ __device__ inline unsigned long long sel_signal(int bad, int count, int
     return 1ull | ((unsigned long long)(bad & 3) << 1) | ((unsigned long long)(count & 0x3fff) << 3) | ((unsigned long long)(mono & 0x3fff) << 17) |
            ((unsigned long long)check << 32);
 }
+inline bool sel_signal_done(unsigned long long w) { return (w & 1) != 0; }
+inline int sel_signal_bad(unsigned long long w) { return (int)((w >> 1) & 3); }
+inline int sel_signal_count(unsigned long long w) { return (int)((w >> 3) & 0x3fffu); }
+inline int sel_signal_mono(unsigned long long w) { return (int)((w >> 17) & 0x3fffu); }
+inline uint32_t sel_signal_check(unsigned long long w) { return (uint32_t)(w >> 32); }
 __host__ __device__ inline uint32_t sel_check(uint32_t packed_sel, uint8_t resp, int pos)
 {
     return (packed_sel ^ ((uint32_t)resp << 24) ^ ((uint32_t)pos * 0x9E3779B1u)) * 0x85EBCA6Bu;
