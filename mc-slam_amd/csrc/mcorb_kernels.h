@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 #include "mcorb_common.h"
+#include "mcorb_signal.h"
 
 namespace mcorb {
 
@@ -77,24 +78,7 @@ void launch_assemble(hipStream_t st, const uint32_t *sel_val, const int *sel_cnt
                      uint32_t *sel, uint8_t *resp, int *nsel, int *mono, int *fallback, int nimg,
                      // optional (all or none): host-mapped copies of sel / resp and a per-image signal word set behind them
                      uint32_t *sel_h = nullptr, uint8_t *resp_h = nullptr, unsigned long long *sig_h = nullptr);
-// The signal word of an image (k_assemble -> host, small batches): bit 0 done, bits 1 - 2 fallback code (1: a level the GPU could not
-// select, 2: more than kcap keypoints), bits 3 - 16 keypoint count, bits 17 - 30 monoIndex (both < 16384: kSelSignalMaxCount),
-// bits 32 - 63 the XOR of sel_check() over the image's keypoints.
-constexpr int kSelSignalMaxCount = 16383;
-__host__ __device__ inline unsigned long long sel_signal(int bad, int count, int mono, uint32_t check)
-{
-    return 1ull | ((unsigned long long)(bad & 3) << 1) | ((unsigned long long)(count & 0x3fff) << 3) | ((unsigned long long)(mono & 0x3fff) << 17) |
-           ((unsigned long long)check << 32);
-}
-inline bool sel_signal_done(unsigned long long w) { return (w & 1) != 0; }
-inline int sel_signal_bad(unsigned long long w) { return (int)((w >> 1) & 3); }
-inline int sel_signal_count(unsigned long long w) { return (int)((w >> 3) & 0x3fffu); }
-inline int sel_signal_mono(unsigned long long w) { return (int)((w >> 17) & 0x3fffu); }
-inline uint32_t sel_signal_check(unsigned long long w) { return (uint32_t)(w >> 32); }
-__host__ __device__ inline uint32_t sel_check(uint32_t packed_sel, uint8_t resp, int pos)
-{
-    return (packed_sel ^ ((uint32_t)resp << 24) ^ ((uint32_t)pos * 0x9E3779B1u)) * 0x85EBCA6Bu;
-}
+// (the signal word of an image, k_assemble -> host: mcorb_signal.h)
 // test hook: std::sort's permutation of n 64-bit entries (upper halves compared) by one wave (wave_std_sort)
 hipError_t sort_selftest(const uint64_t *in_dev, int n, uint64_t *out_dev);
 

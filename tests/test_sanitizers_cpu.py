@@ -34,3 +34,15 @@ def test_sort_model_equals_std_sort():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "bad=0" in out.stdout and "heap_cases=0" not in out.stdout
+
+
+def test_signal_word_layout_and_checksum():
+    """mcorb_signal.h: the word k_assemble hands the host per image (done / fallback / count / monoIndex / checksum) round-trips at its
+    extremes, and the checksum notices a changed, stale or swapped entry"""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_signal")
+    src = [os.path.join(ROOT, "tests", "cpp", "test_signal.cpp"), os.path.join(ROOT, "mc-slam_amd", "csrc", "mcorb_signal.h")]
+    if not os.path.exists(exe) or any(os.path.getmtime(s) > os.path.getmtime(exe) for s in src):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                               "-I" + os.path.join(ROOT, "mc-slam_amd", "csrc"), src[0], "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout + out.stderr
