@@ -139,7 +139,7 @@ struct Slot {
     // mcorb_common.h): written to d_tbl by the kernel, brought to the pinned h_tbl by one DMA per batch
     int *d_tbl = nullptr, *h_tbl = nullptr;
     int tbl_ints_per_image = 0;
-    const int *tbl(int m) const { return h_tbl + (size_t)m * tbl_ints_per_image; }
+    const int *tbl(int img) const { return h_tbl + (size_t)img * tbl_ints_per_image; }
     volatile uint32_t touch_sink[16] = {};
     KnnRow *d_knn = nullptr;         // k-NN rows per pair (device; read back only by mcorb_rig_get_pair_knn2)
     uint32_t *h_mlist = nullptr;     // per pair: accepted (query << 16 | train), query order (k_knn2_finalize)
