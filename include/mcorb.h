@@ -178,6 +178,9 @@ int mcorb_rig_last_timing(mcorb_rig *r, int slot, float us[10]);
 /* MCORB_SELECT_HOST or MCORB_SELECT_GPU: what this rig runs; jobs of a slot that fell back to the host stage so far */
 int mcorb_rig_select_mode(mcorb_rig *r);
 int mcorb_rig_select_fallbacks(mcorb_rig *r, int slot);
+/* small batches (results through host-mapped memory): images whose early read the signal word's checksum rejected so far -- their
+ * keypoint records were built after the job's end event instead (0 in every run so far) */
+int mcorb_rig_early_reads_rejected(mcorb_rig *r, int slot);
 /* MCORB_SELECT_GPU only: a job is the same ~20 launches and copies every time, so a slot captures it once into a HIP graph and
  * replays it with one call.  every = 0: never (launch by launch, per-kernel HIP events: mcorb_rig_last_timing is complete),
  * 1: every job (last_timing reports [0] = the whole job, the rest 0), K > 1: all but every K-th job of a slot, which runs

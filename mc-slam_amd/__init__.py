@@ -314,6 +314,10 @@ class Rig:
         """jobs of the slot the host stage had to redo (a level whose tree went below the GPU bucketing depth)"""
         return int(self.L.mcorb_rig_select_fallbacks(self.h_rig, slot))
 
+    def early_reads_rejected(self, slot=0):
+        """small batches: images whose early read did not match the signal word's checksum (records redone after the end event)"""
+        return int(self.L.mcorb_rig_early_reads_rejected(self.h_rig, slot))
+
     def timing(self, slot=0):
         t = (C.c_float * 10)()
         _lib.check(self.L.mcorb_rig_last_timing(self.h_rig, slot, t))

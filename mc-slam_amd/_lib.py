@@ -78,6 +78,7 @@ SIGNATURES = {
     "mcorb_rig_last_timing": (_i, [_vp, _i, C.POINTER(_f)]),
     "mcorb_rig_select_mode": (_i, [_vp]),
     "mcorb_rig_select_fallbacks": (_i, [_vp, _i]),
+    "mcorb_rig_early_reads_rejected": (_i, [_vp, _i]),
     "mcorb_rig_set_graph": (_i, [_vp, _i]),
     "mcorb_dev_sort_selftest": (_i, [_i, _vp, _i, _vp, _vp]),
     "mcorb_rig_match_pairs_external": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _f, _f]),

@@ -401,6 +401,11 @@ int mcorb_rig_select_fallbacks(mcorb_rig *r, int slot)
     if (!r || slot < 0 || slot >= (int)r->rig.slots.size()) return MCORB_E_ARG;
     return r->rig.slots[slot]->fallbacks;
 }
+int mcorb_rig_early_reads_rejected(mcorb_rig *r, int slot)
+{
+    if (!r || slot < 0 || slot >= (int)r->rig.slots.size()) return MCORB_E_ARG;
+    return r->rig.slots[slot]->stale_reads;
+}
 int mcorb_dev_sort_selftest(int device, const uint32_t *keys, int n, uint32_t *perm_dev, uint32_t *perm_std)
 {
     if (n < 0 || n > 6000 || (n && (!keys || !perm_dev || !perm_std))) { set_error("sort_selftest: bad argument"); return MCORB_E_ARG; }
