@@ -43,12 +43,14 @@ def measure(mcorb, C=4, W=1280, H=720, N=2000, frames=200, distinct=8):
         t2 = time.perf_counter()
         if k >= 10:
             s_up.append(t1 - t0); s_proc.append(t2 - t1)
+    rejected = rig.early_reads_rejected()
     rig.close()
     ms = lambda a: round(float(np.median(a)) * 1e3, 4)
     return {"frames": frames, "upload_ms": ms(t_up), "extract_match_ms": ms(t_proc), "readback_ms": ms(t_get),
             "total_ms": ms(t_all), "total_p95_ms": round(float(np.percentile(t_all, 95)) * 1e3, 4),
             "separated": {"upload_incl_dma_ms": ms(s_up), "extract_match_ms": ms(s_proc),
                           "note": "stream drained behind the upload: the PCIe transfer is in the first figure, not the second"},
+            "early_reads_rejected": rejected,
             "keypoints": [int(len(f[1])) for f in feats], "tracks": int(len(tr)),
             "last_timing_us": {k: round(float(v), 1) for k, v in tm.items()}}
 
